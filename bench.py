@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the Smith-Waterman database search on N MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (swg_search: int16 fill, saturation re-score when
+possible, top-K) over one resident synthetic database; for N > 1 every rank owns an
+independent shard of the same shape (weak scaling, no data-path collective) and the only
+exchange is one RCCL max-all-reduce of the n*K top-K keys per step.
+
+The JSON line carries BASELINE.json's metric (GCUPS = lq * sum(len) / t / 1e9 over real
+residues), the HBM roofline of the fill kernel, and the reference's own AVX2+OpenMP fill
+timed on this host (oracle/_ref, built from the reference's sources) as `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import swg_loader  # noqa: E402
+
+# (query length, sequences, matrix); gaps are the tool defaults -2/-1
+CONFIGS = {
+    1: dict(lq=128, n=1024, matrix="BLOSUM62"),
+    2: dict(lq=367, n=100000, matrix="PAM250"),
+    3: dict(lq=500, n=570000, matrix="BLOSUM62"),
+    4: dict(lq=3000, n=1250000, matrix="BLOSUM62"),   # one GPU's eighth of the 10M-sequence DB
+    5: dict(lq=8192, n=100000, matrix="BLOSUM62", similar=0.01),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--max-waves", type=int, default=0)
+    ap.add_argument("--workgroups", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib_path = os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so")
+    if not os.path.exists(lib_path):
+        if rank == 0:
+            swg_loader.build_module().build()
+        if world > 1:
+            dist.barrier()
+    swg = swg_loader.load()
+
+    cfg = CONFIGS[args.config]
+    lq, n = cfg["lq"], cfg["n"]
+    sc = swg.load_scoring(cfg["matrix"])
+    seed = 0x5EED0000 + args.config
+    q = swg.synth_query(seed, lq)
+    shard_seed = seed + 0x10000 * rank          # every rank: an independent shard of the same shape
+    if cfg.get("similar"):
+        flat, off, _ = swg.synth_db(shard_seed, n, query=q, fraction=cfg["similar"], subst=0.05)
+    else:
+        flat, off = swg.synth_db(shard_seed, n)
+
+    ctx = swg.Context(local_rank)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    ctx.set_option("cols_per_wave", args.cols)
+    ctx.set_option("max_waves", args.max_waves)
+    ctx.set_option("workgroups", args.workgroups)
+    db = swg.Database(flat, off).upload(ctx)
+    residues = int(db.residues)
+
+    K = args.topk
+    keybuf = torch.zeros(world * K, dtype=torch.int64, device="cuda") if world > 1 else None
+
+    def step():
+        _, hits, st = ctx.search(db, want_scores=False, k=K)
+        if world > 1:
+            # global top-K: each rank fills its own K-slot segment, one max-all-reduce over xGMI
+            mine = torch.tensor([swg.hit_key(s, i) for s, i in hits] + [0] * (K - len(hits)), dtype=torch.int64)
+            keybuf.zero_()
+            keybuf[rank * K:(rank + 1) * K] = mine.cuda()
+            dist.all_reduce(keybuf, op=dist.ReduceOp.MAX)
+            hits = swg.topk_merge_keys(keybuf.cpu().numpy().astype(np.uint64), K)
+        return hits, st
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    fill_ms, total_ms, last = [], [], None
+    for _ in range(args.steps):
+        hits, st = step()
+        fill_ms.append(st["fill_ms"])
+        total_ms.append(st["total_ms"])
+        last = st
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    cells_local = lq * residues
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([cells_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cells_total = float(c.item())
+    else:
+        cells_total = float(cells_local)
+
+    if rank == 0:
+        gcups = cells_total * args.steps / elapsed / 1e9
+        k_ms = float(np.mean(fill_ms))
+        bytes_alg = int(last["bytes_alg"])
+        achieved = bytes_alg / (k_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                traffic = tj.get("config%d" % args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # the binding roof is integer VALU, reported beside the (by construction tiny) HBM fraction
+        ops_per_cell = 5.5 if last["path_bits"] == 16 else 13.0
+        valu_peak = 256 * 4 * 32 * 2.4e9          # lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+        kernel_gcups = cells_local / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "GCUPS (DP cell updates/s) at 1/2/4/8 MI355X; bit-exact max scores vs CPU ref",
+            "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16" if last["path_bits"] == 16 else "int32", "data": "synthetic",
+            "config": {
+                "workload": "config %d: 1 query (%d aa) vs %d-seq synthetic protein DB per GPU, %s, gaps -2/-1, top-%d"
+                            % (args.config, lq, n, cfg["matrix"], K),
+                "lq": lq, "n_seqs_per_gpu": n, "residues_per_gpu": residues, "matrix": cfg["matrix"],
+                "cols_per_wave": last["cols_per_wave"], "waves": last["waves"], "passes": last["passes"],
+                "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
+                "cells_padded_over_real": round(last["cells_padded"] / max(1, last["cells"]), 4),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "kernel": "swg_fill_kernel<CellsI%d>" % last["path_bits"], "kernel_ms": round(k_ms, 4),
+                "bytes_alg_per_launch": bytes_alg,
+                "binding_roof": {"bound": "valu_int", "kernel_gcups": round(kernel_gcups, 2),
+                                 "ops_per_cell": ops_per_cell,
+                                 "frac": round(kernel_gcups * 1e9 * ops_per_cell / valu_peak, 4)},
+            },
+            "kernel_ms": {"fill": round(k_ms, 4), "search_total": round(float(np.mean(total_ms)), 4),
+                          "rescore": round(float(last["rescore_ms"]), 4), "topk_host": round(float(last["topk_ms"]), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(swg, q, flat, off, sc, lq)
+        print(json.dumps(out), flush=True)
+
+    db.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(swg, q, flat, off, sc, lq):
+    """The reference's own fill (oracle/_ref: its alignment.c compiled from its sources,
+    dispatched as its driver does) on this host's cores, over a bounded sample of the
+    same database: whole 16-record groups, evenly spaced, about 3e10 cells."""
+    orc = swg_loader.oracle()
+    n = len(off) - 1
+    groups = n // 16
+    budget_cells = 3.0e10
+    total_cells = float(lq) * float(off[-1])
+    take = max(1, min(groups, int(groups * budget_cells / max(total_cells, 1.0))))
+    sel = np.unique(np.linspace(0, groups - 1, take).astype(np.int64))
+    lens = np.diff(off.astype(np.int64))
+    table = sc.table()
+    if orc.have_ref():
+        batches = []
+        cells = 0
+        for g in sel:
+            seqs = [flat[int(off[i]):int(off[i + 1])] for i in range(g * 16, g * 16 + 16)]
+            batches.append(orc.make_batch16(seqs))
+            cells += lq * int(lens[g * 16:g * 16 + 16].sum())
+        threads = orc.rlib().swref_max_threads()
+        orc.ref_batches(q, batches[:min(len(batches), 64)], table, -2, -1)      # warm the pages
+        _, secs = orc.ref_batches(q, batches, table, -2, -1)
+        return {"value": round(cells / secs / 1e9, 3), "unit": "GCUPS", "cores": int(threads), "kind": "reference",
+                "sample": "%d of %d 16-record batches of the same DB (%.3g real cells), reference "
+                          "alignment_fill_matrices under its OpenMP dynamic dispatch, fill region only"
+                          % (len(batches), groups, cells)}
+    # no reference build on this box: time the scalar oracle instead (a port, much slower)
+    idx = np.concatenate([np.arange(g * 16, g * 16 + 16) for g in sel[:max(1, len(sel) // 16)]])
+    sub_off = np.zeros(len(idx) + 1, dtype=np.uint64)
+    sub_off[1:] = np.cumsum(lens[idx])
+    sub_flat = np.concatenate([flat[int(off[i]):int(off[i + 1])] for i in idx])
+    t0 = time.perf_counter()
+    orc.score_db(q, sub_flat, sub_off, table, -2, -1)
+    secs = time.perf_counter() - t0
+    return {"value": round(lq * float(sub_off[-1]) / secs / 1e9, 3), "unit": "GCUPS",
+            "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d sequences of the same DB, scalar int32 oracle with OpenMP" % len(idx)}
+
+
+if __name__ == "__main__":
+    main()

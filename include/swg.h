@@ -1,0 +1,170 @@
+/*
+ * swg.h -- C ABI of libswg: MI355X-native Smith-Waterman protein database search.
+ *
+ * This is the drop-in boundary for the one hot path of Aseeef/seq-align-gpu:
+ * the affine-gap three-state fill `alignment_fill_matrices`
+ * (reference src/alignment.c:47-187) as it is driven, one query against a
+ * database, by the OpenMP batch-of-batches loop at
+ * reference src/alignment_cmdline.c:501-509.  Plain pointers and sizes only;
+ * no C++ or torch types; no function here aborts or exits the process (the
+ * reference asserts/exit()s: src/alignment.c:63-66, src/alignment_scoring.c:78-79)
+ * -- every entry point returns 0 or a negative swg_status and leaves a message
+ * retrievable with swg_last_error()/swg_global_error().
+ *
+ * Residues are exchanged as the reference's substitution-table indices
+ * (`letters_to_index`, reference src/alignment_scoring.c:70-81): 1..26 for
+ * A..Z case-folded, 31 for '*'.  Index 0 is reserved by this library as the
+ * padding residue and is rejected in input.
+ *
+ * Threading: a swg_ctx is not thread-safe; distinct contexts may be used from
+ * distinct threads (the reference's fill is re-entrant per aligner_t,
+ * src/alignment_cmdline.c:504-507).  All calls are synchronous at the ABI.
+ */
+#ifndef SWG_H
+#define SWG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWG_ABI_VERSION 1
+
+typedef enum swg_status {
+    SWG_OK = 0,
+    SWG_ERR_ARG = -1,     /* bad argument (NULL, zero length, out-of-range value) */
+    SWG_ERR_HIP = -2,     /* HIP runtime / launch failure; text in swg_last_error */
+    SWG_ERR_NOMEM = -3,   /* host or device allocation failed */
+    SWG_ERR_STATE = -4,   /* call order violated (no scoring / no query / db not resident) */
+    SWG_ERR_RESIDUE = -5, /* residue index outside 1..31 (reference: exit(1) in letters_to_index) */
+    SWG_ERR_IO = -6,      /* file could not be read / parsed (host helpers) */
+    SWG_ERR_NODEVICE = -7 /* no usable GPU: the product path never falls back to the CPU */
+} swg_status;
+
+typedef struct swg_ctx swg_ctx; /* one GPU, one stream, one query + scoring system */
+typedef struct swg_db swg_db;   /* length-sorted, binned, dword-packed database (shard) */
+
+typedef struct swg_config {
+    int device;      /* HIP device ordinal */
+    int reserved[7]; /* must be zero */
+} swg_config;
+
+/* One hit of the top-K report.  Order: higher score first, ties by lower
+ * database index (total order => deterministic across shards and GPUs). */
+typedef struct swg_hit {
+    int32_t score;
+    uint32_t index; /* ORIGINAL database index (position in the caller's input) */
+} swg_hit;
+
+/* Filled by swg_search.  Times are device times from HIP events on the
+ * library's stream; the reference's `Total Time` likewise counts only the fill
+ * (src/alignment_cmdline.c:503-509). */
+typedef struct swg_stats {
+    uint64_t cells;         /* lq * sum(len_i): real cells, what GCUPS counts */
+    uint64_t cells_padded;  /* cells actually computed (bin + strip padding) */
+    uint64_t bytes_alg;     /* algorithmic HBM bytes of the fill */
+    uint64_t n_rescored;    /* sequences re-scored in int32 after int16 saturation */
+    double fill_ms;         /* 16-bit fill kernel (or the int32 fill when forced) */
+    double rescore_ms;      /* overflow collection + int32 re-score */
+    double topk_ms;         /* device top-K selection */
+    double total_ms;        /* first kernel start .. last kernel end */
+    int32_t path_bits;      /* 16 or 32: arithmetic of the main fill */
+    int32_t cols_per_wave;  /* K: query columns held in registers per wavefront */
+    int32_t waves;          /* W: wavefronts of one systolic workgroup */
+    int32_t passes;         /* query passes (ceil(lq / (W*K))) */
+    int32_t workgroups;     /* grid size of the fill */
+    int32_t reserved[3];
+} swg_stats;
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Create a context on cfg->device.  Fails with SWG_ERR_NODEVICE when there is
+ * no GPU -- there is deliberately no CPU backend behind this ABI. */
+int swg_create(const swg_config *cfg, swg_ctx **out);
+void swg_destroy(swg_ctx *ctx);
+const char *swg_last_error(const swg_ctx *ctx);
+const char *swg_global_error(void); /* errors of calls that have no context */
+int swg_abi_version(void);
+
+/* Tuning / test switches.  Keys: "force_bits" (0 auto | 16 | 32),
+ * "cols_per_wave" (0 auto | 8..64, multiple of 4), "max_waves" (0 auto | 1..16),
+ * "workgroups" (0 auto). */
+int swg_set_option(swg_ctx *ctx, const char *key, long value);
+
+/* Replaces scoring_t for the path (reference src/alignment_scoring.h:21-37):
+ * sub[a][b] = score of query residue index a against database residue index b
+ * (row = query: src/alignment.c:33,41); gap of length n costs
+ * gap_open + n*gap_extend (src/alignment_scoring.c:35-36). */
+int swg_set_scoring(swg_ctx *ctx, const int8_t sub[32][32], int gap_open, int gap_extend);
+
+/* Replaces the query half of aligner_create (src/alignment.h:64-68):
+ * idx[lq] are table indices; the library copies them. */
+int swg_set_query(swg_ctx *ctx, const int8_t *idx, size_t lq);
+
+/* ---- database --------------------------------------------------------- */
+
+/* Host-only (needs no GPU).  Replaces the 16-lane transpose+pad packer of
+ * reference src/alignment_cmdline.c:429-452: sequences are sorted by length
+ * (descending, stable), grouped into bins of 128, and stored row-major as one
+ * dword per 4 residues per sequence so that a wavefront's loads are coalesced.
+ * flat[offsets[i] .. offsets[i+1]) are the indices of sequence i.
+ * shard_count > 1 keeps only bins b with b % shard_count == shard_rank of the
+ * GLOBAL bin sequence (round-robin over GPUs: adjacent bins have near-equal
+ * work); indices reported later are always original ones. */
+int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n,
+                int shard_rank, int shard_count, swg_db **out);
+int swg_db_upload(swg_ctx *ctx, swg_db *db); /* H2D; db becomes resident on ctx's GPU */
+void swg_db_free(swg_db *db);
+size_t swg_db_count(const swg_db *db);          /* sequences in this shard */
+size_t swg_db_total_count(const swg_db *db);    /* sequences given to swg_db_pack */
+uint64_t swg_db_residues(const swg_db *db);     /* sum of lengths in this shard */
+uint64_t swg_db_packed_bytes(const swg_db *db); /* bytes resident in HBM */
+/* original index of the i-th sequence of this shard in its sorted order */
+const uint32_t *swg_db_order(const swg_db *db);
+
+/* ---- the hot path ----------------------------------------------------- */
+
+/* Replaces the whole timed region of the reference
+ * (src/alignment_cmdline.c:503-509) plus the read-out of aligner->max_scores
+ * (src/tools/sw_cmdline.c:55-72) for every sequence of `db`:
+ *   scores_out  NULL, or an array of swg_db_total_count(db) int32 indexed by
+ *               ORIGINAL database index; only this shard's entries are written.
+ *   topk_out/k  NULL/0, or room for k hits of this shard (fewer are written
+ *               when the shard is smaller; *n_hits tells how many).
+ * Scores are exact int32 local-alignment maxima: the int16 kernel flags every
+ * sequence whose score saturates and those are re-scored in int32. */
+int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out,
+               swg_hit *topk_out, size_t k, size_t *n_hits, swg_stats *stats);
+
+/* Reference-shaped replay of the call site itself: n_batches 16-lane batches
+ * exactly as `alignment_fill_matrices` receives them -- db_idx_t is
+ * aligner_t.seq_b_batch_indexes, [max_len][16] int8 (src/alignment.h:28,
+ * src/alignment_cmdline.c:434,445), padded rows included and computed as real
+ * rows like the reference does; max_scores receives
+ * aligner_t.max_scores for lanes 0..vector_size-1, saturated to int16.
+ * Uses the scoring and query already set on ctx. */
+typedef struct swg_batch16 {
+    const int8_t *db_idx_t;
+    size_t max_len;
+    size_t vector_size;
+    int16_t *max_scores;
+} swg_batch16;
+int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches,
+                       double *fill_seconds);
+
+/* ---- multi-GPU merge -------------------------------------------------- */
+
+/* 64-bit sort key of a hit: (score << 32) | (0xFFFFFFFF - index).  Larger key =
+ * better hit, so one max-all-reduce (RCCL, ncclMax on n_gpus*k keys) or one
+ * all-gather merges the shards' top-K lists. */
+uint64_t swg_hit_key(int32_t score, uint32_t index);
+void swg_key_hit(uint64_t key, swg_hit *out);
+/* keys[n] (zeros ignored) -> best k hits, sorted.  Returns hits written. */
+size_t swg_topk_merge_keys(const uint64_t *keys, size_t n, size_t k, swg_hit *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWG_H */

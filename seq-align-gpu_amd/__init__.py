@@ -1,0 +1,343 @@
+"""ctypes binding of libswg (include/swg.h, include/swg_host.h).
+
+This package is plumbing for tests and bench.py: the product is the C-ABI
+library next to this file.  Nothing here computes an alignment; if libswg.so
+is missing the import fails loudly, and `Context()` raises when there is no
+GPU (the library has no CPU backend).
+
+The directory name has a hyphen (it is the name the build contract gives), so
+it is imported through `swg_loader.load()` at the repo root, as module
+`seq_align_gpu_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswg.so")
+DATA_DIR = os.path.join(_HERE, "data")
+CLI_PATH = os.path.join(_HERE, "bin", "smith_waterman")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libswg.so is not built: run `python seq-align-gpu_amd/build.py` "
+        "(or __graft_entry__.build()); there is no Python/CPU fallback")
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+SWG_OK, SWG_ERR_ARG, SWG_ERR_HIP, SWG_ERR_NOMEM = 0, -1, -2, -3
+SWG_ERR_STATE, SWG_ERR_RESIDUE, SWG_ERR_IO, SWG_ERR_NODEVICE = -4, -5, -6, -7
+
+# every symbol declared in include/swg.h and include/swg_host.h
+ABI_SYMBOLS = [
+    "swg_create", "swg_destroy", "swg_last_error", "swg_global_error", "swg_abi_version",
+    "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_upload",
+    "swg_db_free", "swg_db_count", "swg_db_total_count", "swg_db_residues",
+    "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_fill_batches16", "swg_hit_key",
+    "swg_key_hit", "swg_topk_merge_keys",
+    "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
+    "swg_scoring_load_matrix", "swg_query_sanitize", "swg_seqs_read", "swg_seqs_free",
+    "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar",
+    "swg_synth_free",
+]
+
+
+class SwgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libswg error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("reserved", C.c_int * 7)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("score", C.c_int32), ("index", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("cells", C.c_uint64), ("cells_padded", C.c_uint64), ("bytes_alg", C.c_uint64),
+        ("n_rescored", C.c_uint64), ("fill_ms", C.c_double), ("rescore_ms", C.c_double),
+        ("topk_ms", C.c_double), ("total_ms", C.c_double), ("path_bits", C.c_int32),
+        ("cols_per_wave", C.c_int32), ("waves", C.c_int32), ("passes", C.c_int32),
+        ("workgroups", C.c_int32), ("reserved", C.c_int32 * 3),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class Batch16(C.Structure):
+    _fields_ = [("db_idx_t", C.c_void_p), ("max_len", C.c_size_t), ("vector_size", C.c_size_t),
+                ("max_scores", C.c_void_p)]
+
+
+class Scoring(C.Structure):
+    _fields_ = [("gap_open", C.c_int), ("gap_extend", C.c_int), ("match", C.c_int),
+                ("mismatch", C.c_int), ("sub", (C.c_int8 * 32) * 32), ("set", C.c_uint32 * 32)]
+
+    def table(self):
+        return np.ctypeslib.as_array(self.sub).reshape(32, 32).copy()
+
+
+class Seqs(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("names", C.c_void_p), ("name_off", C.POINTER(C.c_uint64)),
+                ("seq", C.c_void_p), ("seq_off", C.POINTER(C.c_uint64))]
+
+
+def _sig(name, restype, argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = argtypes
+    return f
+
+
+_vp = C.c_void_p
+_sig("swg_create", C.c_int, [C.POINTER(Config), C.POINTER(_vp)])
+_sig("swg_destroy", None, [_vp])
+_sig("swg_last_error", C.c_char_p, [_vp])
+_sig("swg_global_error", C.c_char_p, [])
+_sig("swg_abi_version", C.c_int, [])
+_sig("swg_set_option", C.c_int, [_vp, C.c_char_p, C.c_long])
+_sig("swg_set_scoring", C.c_int, [_vp, _vp, C.c_int, C.c_int])
+_sig("swg_set_query", C.c_int, [_vp, _vp, C.c_size_t])
+_sig("swg_db_pack", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_vp)])
+_sig("swg_db_upload", C.c_int, [_vp, _vp])
+_sig("swg_db_free", None, [_vp])
+_sig("swg_db_count", C.c_size_t, [_vp])
+_sig("swg_db_total_count", C.c_size_t, [_vp])
+_sig("swg_db_residues", C.c_uint64, [_vp])
+_sig("swg_db_packed_bytes", C.c_uint64, [_vp])
+_sig("swg_db_order", C.POINTER(C.c_uint32), [_vp])
+_sig("swg_search", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)])
+_sig("swg_fill_batches16", C.c_int, [_vp, C.POINTER(Batch16), C.c_size_t, C.POINTER(C.c_double)])
+_sig("swg_hit_key", C.c_uint64, [C.c_int32, C.c_uint32])
+_sig("swg_key_hit", None, [C.c_uint64, C.POINTER(Hit)])
+_sig("swg_topk_merge_keys", C.c_size_t, [_vp, C.c_size_t, C.c_size_t, _vp])
+_sig("swg_letter_index", C.c_int, [C.c_int])
+_sig("swg_index_letter", C.c_int, [C.c_int])
+_sig("swg_scoring_init", None, [C.POINTER(Scoring)])
+_sig("swg_scoring_add", C.c_int, [C.POINTER(Scoring), C.c_int, C.c_int, C.c_int])
+_sig("swg_scoring_load_matrix", C.c_int, [C.POINTER(Scoring), C.c_char_p, C.c_char_p, C.c_size_t])
+_sig("swg_query_sanitize", None, [C.POINTER(Scoring), _vp, C.c_size_t])
+_sig("swg_seqs_read", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Seqs), C.c_char_p, C.c_size_t])
+_sig("swg_seqs_free", None, [C.POINTER(Seqs)])
+_sig("swg_seqs_to_indices", C.c_int, [C.POINTER(Seqs), _vp, C.c_char_p])
+_sig("swg_synth_db", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_double, C.c_uint32,
+                               C.c_uint32, C.POINTER(_vp), C.POINTER(_vp)])
+_sig("swg_synth_query", None, [C.c_uint64, C.c_size_t, _vp])
+_sig("swg_synth_db_similar", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_double, C.c_uint32,
+                                       C.c_uint32, _vp, C.c_size_t, C.c_double, C.c_double,
+                                       C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)])
+_sig("swg_synth_free", None, [_vp])
+
+
+def _check(rc, ctx=None):
+    if rc != SWG_OK:
+        msg = lib.swg_last_error(ctx) if ctx else lib.swg_global_error()
+        raise SwgError(rc, (msg or b"").decode("utf-8", "replace"))
+
+
+def _i8(a):
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    return a, a.ctypes.data_as(_vp)
+
+
+# ---------------------------------------------------------------------------
+# host helpers
+# ---------------------------------------------------------------------------
+def letters_to_indices(s):
+    """Reference letters_to_index over a string; raises on an illegal letter."""
+    out = np.empty(len(s), dtype=np.int8)
+    for i, ch in enumerate(s):
+        v = lib.swg_letter_index(ord(ch))
+        if v < 0:
+            raise SwgError(SWG_ERR_RESIDUE, "illegal residue %r" % ch)
+        out[i] = v
+    return out
+
+
+def load_scoring(name_or_path, gap_open=-2, gap_extend=-1):
+    """Scoring struct from a matrix file (bundled name like 'BLOSUM62' or a path)."""
+    path = name_or_path
+    if not os.path.exists(path):
+        path = os.path.join(DATA_DIR, name_or_path + ".txt")
+    sc = Scoring()
+    lib.swg_scoring_init(C.byref(sc))
+    err = C.create_string_buffer(512)
+    rc = lib.swg_scoring_load_matrix(C.byref(sc), path.encode(), err, 512)
+    if rc != SWG_OK:
+        raise SwgError(rc, err.value.decode())
+    sc.gap_open, sc.gap_extend = gap_open, gap_extend
+    return sc
+
+
+def read_seqs(path, max_records=0):
+    """-> (names list, residue letters bytes, offsets uint64[n+1])."""
+    s = Seqs()
+    err = C.create_string_buffer(512)
+    rc = lib.swg_seqs_read(path.encode(), max_records, C.byref(s), err, 512)
+    if rc != SWG_OK:
+        raise SwgError(rc, err.value.decode())
+    try:
+        n = s.n
+        seq_off = np.ctypeslib.as_array(s.seq_off, shape=(n + 1,)).copy()
+        name_off = np.ctypeslib.as_array(s.name_off, shape=(n + 1,)).copy()
+        seq = C.string_at(s.seq, int(seq_off[n])) if n else b""
+        raw = C.string_at(s.names, int(name_off[n])) if n else b""
+        names = [raw[int(name_off[i]):int(name_off[i + 1]) - 1].decode("utf-8", "replace") for i in range(n)]
+        idx = np.empty(len(seq), dtype=np.int8)
+        bad = C.create_string_buffer(2)
+        rc = lib.swg_seqs_to_indices(C.byref(s), idx.ctypes.data_as(_vp), bad)
+        if rc != SWG_OK:
+            raise SwgError(rc, "illegal residue %r" % bad.value)
+    finally:
+        lib.swg_seqs_free(C.byref(s))
+    return names, seq, idx, seq_off
+
+
+def _take(ptr, nbytes, dtype):
+    buf = (C.c_uint8 * nbytes).from_address(ptr.value) if nbytes else None
+    arr = np.frombuffer(buf, dtype=dtype).copy() if nbytes else np.zeros(0, dtype=dtype)
+    lib.swg_synth_free(ptr)
+    return arr
+
+
+def synth_db(seed, n, median=290.0, sigma_ln=0.75, min_len=20, max_len=5000, query=None,
+             fraction=0.0, subst=0.05):
+    """Synthetic database -> (flat int8, offsets uint64[n+1][, n_planted])."""
+    flat, off = _vp(), _vp()
+    if query is None or fraction <= 0.0:
+        _check(lib.swg_synth_db(seed, n, median, sigma_ln, min_len, max_len, C.byref(flat), C.byref(off)))
+        planted = None
+    else:
+        q, qp = _i8(query)
+        npl = C.c_size_t(0)
+        _check(lib.swg_synth_db_similar(seed, n, median, sigma_ln, min_len, max_len, qp, len(q),
+                                        fraction, subst, C.byref(flat), C.byref(off), C.byref(npl)))
+        planted = npl.value
+    offsets = _take(off, (n + 1) * 8, np.uint64)
+    residues = _take(flat, int(offsets[n]), np.int8)
+    return (residues, offsets) if planted is None else (residues, offsets, planted)
+
+
+def synth_query(seed, lq):
+    out = np.empty(lq, dtype=np.int8)
+    lib.swg_synth_query(seed, lq, out.ctypes.data_as(_vp))
+    return out
+
+
+def hit_key(score, index):
+    return int(lib.swg_hit_key(int(score), int(index)))
+
+
+def key_hit(key):
+    h = Hit()
+    lib.swg_key_hit(int(key), C.byref(h))
+    return int(h.score), int(h.index)
+
+
+def topk_merge_keys(keys, k):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    out = (Hit * max(k, 1))()
+    m = lib.swg_topk_merge_keys(keys.ctypes.data_as(_vp), keys.size, k, C.cast(out, _vp))
+    return [(int(out[i].score), int(out[i].index)) for i in range(m)]
+
+
+# ---------------------------------------------------------------------------
+# database + context
+# ---------------------------------------------------------------------------
+class Database:
+    """Host-packed database shard (swg_db); `upload(ctx)` makes it resident."""
+
+    def __init__(self, flat, offsets, shard_rank=0, shard_count=1):
+        self.handle = None
+        self._flat, fp = _i8(flat)
+        self._off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = self._off.size - 1
+        h = _vp()
+        _check(lib.swg_db_pack(fp, self._off.ctypes.data_as(_vp), n, shard_rank, shard_count, C.byref(h)))
+        self.handle = h
+        self._flat = None  # the library copied what it needs
+
+    count = property(lambda self: lib.swg_db_count(self.handle))
+    total_count = property(lambda self: lib.swg_db_total_count(self.handle))
+    residues = property(lambda self: lib.swg_db_residues(self.handle))
+    packed_bytes = property(lambda self: lib.swg_db_packed_bytes(self.handle))
+
+    def order(self):
+        return np.ctypeslib.as_array(lib.swg_db_order(self.handle), shape=(self.count,)).copy()
+
+    def upload(self, ctx):
+        _check(lib.swg_db_upload(ctx.handle, self.handle), ctx.handle)
+        return self
+
+    def close(self):
+        if self.handle:
+            lib.swg_db_free(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+class Context:
+    """swg_ctx: one GPU, one query, one scoring system."""
+
+    def __init__(self, device=0):
+        self.handle = None
+        cfg = Config()
+        cfg.device = device
+        h = _vp()
+        _check(lib.swg_create(C.byref(cfg), C.byref(h)))
+        self.handle = h
+
+    def set_option(self, key, value):
+        _check(lib.swg_set_option(self.handle, key.encode(), int(value)), self.handle)
+
+    def set_scoring(self, sub, gap_open, gap_extend):
+        if isinstance(sub, Scoring):
+            sub = sub.table()
+        s, sp = _i8(np.asarray(sub).reshape(32, 32))
+        _check(lib.swg_set_scoring(self.handle, sp, int(gap_open), int(gap_extend)), self.handle)
+
+    def set_query(self, idx):
+        q, qp = _i8(idx)
+        _check(lib.swg_set_query(self.handle, qp, q.size), self.handle)
+
+    def search(self, db, want_scores=True, k=0):
+        """-> (scores int32[total] or None, hits [(score, index)], stats dict)."""
+        scores = np.zeros(db.total_count, dtype=np.int32) if want_scores else None
+        hits = (Hit * max(k, 1))()
+        nh = C.c_size_t(0)
+        st = Stats()
+        rc = lib.swg_search(self.handle, db.handle, scores.ctypes.data_as(_vp) if want_scores else None,
+                            C.cast(hits, _vp) if k else None, k, C.byref(nh), C.byref(st))
+        _check(rc, self.handle)
+        return scores, [(int(hits[i].score), int(hits[i].index)) for i in range(nh.value)], st.as_dict()
+
+    def fill_batches16(self, batches):
+        """batches: list of (db_idx_t int8[max_len,16], vector_size) -> list of int16[vector_size]."""
+        arr = (Batch16 * len(batches))()
+        keep, outs = [], []
+        for i, (d, vs) in enumerate(batches):
+            d = np.ascontiguousarray(d, dtype=np.int8)
+            o = np.zeros(16, dtype=np.int16)
+            keep.append(d)
+            outs.append(o)
+            arr[i].db_idx_t = d.ctypes.data
+            arr[i].max_len = d.shape[0]
+            arr[i].vector_size = vs
+            arr[i].max_scores = o.ctypes.data
+        secs = C.c_double(0)
+        _check(lib.swg_fill_batches16(self.handle, arr, len(batches), C.byref(secs)), self.handle)
+        return [o[:vs].copy() for o, (_, vs) in zip(outs, batches)], secs.value
+
+    def close(self):
+        if self.handle:
+            lib.swg_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close

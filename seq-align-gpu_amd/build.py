@@ -1,0 +1,111 @@
+"""Build libswg.so (gfx950 kernels + C-ABI + plain-C host helpers) and the
+smith_waterman CLI, in-tree, with explicit compiler invocations.
+
+    python seq-align-gpu_amd/build.py [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The built files are git-ignored
+but travel to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libswg.so")
+CLI = os.path.join(HERE, "bin", "smith_waterman")
+
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+ARCH = "gfx950"
+
+# The SI load/store optimizer would fuse the kernel's conflict-free ds_read_b64
+# pairs into ds_read2_b64, which is banked modulo 32 dwords and runs at half the
+# bytes per clock (MI355X_MICROARCH.md, LDS table): keep it off for device code.
+# (The host half of the compile prints a harmless "not a recognized feature".)
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+
+HIP_SOURCES = ["swg_kernels.hip", "swg_api.cpp"]
+CXX_SOURCES = ["swg_pack.cpp"]  # host-only C++, OpenMP via g++
+C_SOURCES = ["swg_scoring.c", "swg_seqio.c", "swg_synth.c"]
+CLI_SOURCES = ["sw_cmdline.c"]
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    out = "\n".join(l for l in r.stdout.splitlines() if "not a recognized feature" not in l)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), out))
+    if out.strip():
+        print(out)
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _headers():
+    hs = []
+    for d in (CSRC, HOST, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                hs.append(os.path.join(d, f))
+    return hs
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    hdrs = _headers() + [os.path.abspath(__file__)]
+    objs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src + ".o")
+        if force or _stale(o, [s] + hdrs):
+            if verbose:
+                print("[hipcc]", src)
+            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-c"]
+                 + DEVICE_FLAGS + ["-o", o, "-x", "hip", s])
+        objs.append(o)
+    for src in CXX_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src + ".o")
+        if force or _stale(o, [s] + hdrs):
+            if verbose:
+                print("[g++]", src)
+            _run(["g++", "-O2", "-fPIC", "-fopenmp", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                  "-I" + os.path.join(ROCM, "include"), "-c", "-o", o, s])
+        objs.append(o)
+    for src in C_SOURCES:
+        s = os.path.join(HOST, src)
+        o = os.path.join(OBJ, src + ".o")
+        if force or _stale(o, [s] + hdrs):
+            if verbose:
+                print("[gcc]", src)
+            _run(["gcc", "-O2", "-fPIC", "-fopenmp", "-std=c11", "-Wall", "-c", "-o", o, s])
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        if verbose:
+            print("[link] libswg.so")
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+             + ["-lgomp", "-lz", "-lm"])
+    cli_srcs = [os.path.join(HOST, s) for s in CLI_SOURCES if os.path.exists(os.path.join(HOST, s))]
+    if cli_srcs and (force or _stale(CLI, cli_srcs + [LIB] + hdrs)):
+        if verbose:
+            print("[gcc] smith_waterman")
+        _run(["gcc", "-O2", "-std=c11", "-Wall", "-o", CLI] + cli_srcs
+             + ["-L" + HERE, "-lswg", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+                "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-lz", "-lm"])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("ok:", LIB)

@@ -1,0 +1,545 @@
+// swg_api.cpp -- the C-ABI of include/swg.h over the gfx950 kernels.
+//
+// Replaces, for one query against a whole database, the reference's timed
+// region `#pragma omp parallel for ... alignment_fill_matrices(aligners[i])`
+// (src/alignment_cmdline.c:503-509) and the aligner_create/aligner_update
+// bookkeeping in front of it (src/alignment.c:190-233).  There is no CPU
+// fallback in this file: without a GPU swg_create fails with SWG_ERR_NODEVICE.
+#include "swg_host_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+int swg_set_global_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return swg_set_ctx_error(ctx, e_ == hipErrorOutOfMemory ? SWG_ERR_NOMEM : SWG_ERR_HIP, \
+                                     "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                                     __FILE__, __LINE__);                                       \
+    } while (0)
+
+extern "C" const char *swg_last_error(const swg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+extern "C" const char *swg_global_error(void) { return g_err.c_str(); }
+extern "C" int swg_abi_version(void) { return SWG_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
+{
+    if (!out) return swg_set_global_error(SWG_ERR_ARG, "swg_create: out is NULL");
+    *out = nullptr;
+    const int dev = cfg ? cfg->device : 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return swg_set_global_error(SWG_ERR_NODEVICE,
+                                    "swg_create: no HIP device (%s); libswg has no CPU backend",
+                                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (dev < 0 || dev >= n)
+        return swg_set_global_error(SWG_ERR_ARG, "swg_create: device %d out of range (have %d)", dev, n);
+    swg_ctx *ctx = new (std::nothrow) swg_ctx();
+    if (!ctx) return swg_set_global_error(SWG_ERR_NOMEM, "swg_create: out of memory");
+    ctx->device = dev;
+    memset(ctx->sub, 0, sizeof ctx->sub);
+    int rc = [&]() -> int {
+        HIP_TRY(ctx, hipSetDevice(dev));
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, dev));
+        ctx->n_cu = prop.multiProcessorCount;
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        for (auto &ev : ctx->ev) HIP_TRY(ctx, hipEventCreate(&ev));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_sub, 32 * 32));
+        return SWG_OK;
+    }();
+    if (rc != SWG_OK) {
+        g_err = ctx->err;
+        swg_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return SWG_OK;
+}
+
+extern "C" void swg_destroy(swg_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_sub);
+    (void)hipFree(ctx->d_query);
+    (void)hipFree(ctx->d_profile[0]);
+    (void)hipFree(ctx->d_profile[1]);
+    (void)hipFree(ctx->d_scratch);
+    for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
+{
+    if (!ctx || !key) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_set_option: NULL argument");
+    if (!strcmp(key, "force_bits")) {
+        if (value != 0 && value != 16 && value != 32)
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "force_bits must be 0, 16 or 32");
+        ctx->opt_force_bits = value;
+    } else if (!strcmp(key, "cols_per_wave")) {
+        ctx->opt_cols = value;
+    } else if (!strcmp(key, "max_waves")) {
+        if (value < 0 || value > 16) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "max_waves must be 0..16");
+        ctx->opt_max_waves = value;
+    } else if (!strcmp(key, "workgroups")) {
+        if (value < 0) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "workgroups must be >= 0");
+        ctx->opt_workgroups = value;
+    } else {
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_set_option: unknown key '%s'", key);
+    }
+    return SWG_OK;
+}
+
+extern "C" int swg_set_scoring(swg_ctx *ctx, const int8_t sub[32][32], int gap_open, int gap_extend)
+{
+    if (!ctx || !sub) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_set_scoring: NULL argument");
+    if (gap_open < -32768 || gap_open > 32767 || gap_extend < -32768 || gap_extend > 32767)
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG,
+                                 "swg_set_scoring: gap scores must fit the reference's int16 score_t");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    memcpy(ctx->sub, sub, 32 * 32);
+    ctx->gap_open = gap_open;
+    ctx->gap_extend = gap_extend;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sub, ctx->sub, 32 * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_scoring = true;
+    ctx->epoch++;
+    return SWG_OK;
+}
+
+extern "C" int swg_set_query(swg_ctx *ctx, const int8_t *idx, size_t lq)
+{
+    if (!ctx || !idx || lq == 0)
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_set_query: NULL or empty query");
+    if (lq > (1u << 24)) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_set_query: query too long");
+    for (size_t i = 0; i < lq; ++i)
+        if (idx[i] < 1 || idx[i] > 31)
+            return swg_set_ctx_error(ctx, SWG_ERR_RESIDUE,
+                                     "swg_set_query: residue index %d at %zu outside 1..31", idx[i], i);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (lq > ctx->d_query_cap) {
+        (void)hipFree(ctx->d_query);
+        ctx->d_query = nullptr;
+        ctx->d_query_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_query, lq));
+        ctx->d_query_cap = lq;
+    }
+    ctx->query.assign(idx, idx + lq);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_query, ctx->query.data(), lq, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->epoch++;
+    return SWG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// database residency
+// ---------------------------------------------------------------------------
+void swg_db_release_device(swg_db *db)
+{
+    if (!db || db->device < 0) return;
+    (void)hipSetDevice(db->device);
+    (void)hipFree(db->d_packed);
+    (void)hipFree(db->d_bin_off);
+    (void)hipFree(db->d_bin_nblk);
+    (void)hipFree(db->d_order);
+    (void)hipFree(db->d_scores);
+    (void)hipFree(db->d_list);
+    (void)hipFree(db->d_counters);
+    (void)hipFree(db->d_keys);
+    db->d_packed = nullptr;
+    db->d_bin_off = nullptr;
+    db->d_bin_nblk = nullptr;
+    db->d_order = nullptr;
+    db->d_scores = nullptr;
+    db->d_list = nullptr;
+    db->d_counters = nullptr;
+    db->d_keys = nullptr;
+    db->device = -1;
+}
+
+extern "C" int swg_db_upload(swg_ctx *ctx, swg_db *db)
+{
+    if (!ctx || !db) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_db_upload: NULL argument");
+    swg_db_release_device(db);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    db->device = ctx->device;
+    const size_t nb = db->n_bins, ns = nb * SWG_BIN;
+    int rc = [&]() -> int {
+        HIP_TRY(ctx, hipMalloc(&db->d_packed, std::max<size_t>(4, db->packed.size() * 4)));
+        HIP_TRY(ctx, hipMalloc(&db->d_bin_off, std::max<size_t>(8, nb * 8)));
+        HIP_TRY(ctx, hipMalloc(&db->d_bin_nblk, std::max<size_t>(4, nb * 4)));
+        HIP_TRY(ctx, hipMalloc(&db->d_order, std::max<size_t>(4, ns * 4)));
+        HIP_TRY(ctx, hipMalloc(&db->d_scores, std::max<size_t>(4, ns * 4)));
+        HIP_TRY(ctx, hipMalloc(&db->d_list, std::max<size_t>(4, ns * 4)));
+        HIP_TRY(ctx, hipMalloc(&db->d_counters, 64));
+        if (nb) {
+            HIP_TRY(ctx, hipMemcpyAsync(db->d_packed, db->packed.data(), db->packed.size() * 4,
+                                        hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(db->d_bin_off, db->bin_off.data(), nb * 8,
+                                        hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(db->d_bin_nblk, db->bin_nblk.data(), nb * 4,
+                                        hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(db->d_order, db->order.data(), ns * 4, hipMemcpyHostToDevice,
+                                        ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return SWG_OK;
+    }();
+    if (rc != SWG_OK) swg_db_release_device(db);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// planning
+// ---------------------------------------------------------------------------
+struct Plan {
+    int bits, variant, K, W, npass, workgroups;
+    SwgKernelInfo info;
+};
+
+static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
+{
+    const int nv = swg_num_variants(bits);
+    int variant = 0;
+    if (ctx->opt_cols > 0) {
+        variant = -1;
+        for (int v = 0; v < nv; ++v)
+            if (swg_variant_info(bits, v).K == (int)ctx->opt_cols) variant = v;
+        if (variant < 0)
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "cols_per_wave=%ld not built for the %d-bit path",
+                                     ctx->opt_cols, bits);
+    }
+    const SwgKernelInfo info = swg_variant_info(bits, variant);
+    int maxw = info.max_waves;
+    if (ctx->opt_max_waves > 0) maxw = std::min<int>(maxw, (int)ctx->opt_max_waves);
+    const size_t lq = ctx->query.size();
+    const size_t cols_per_pass_max = (size_t)maxw * info.K;
+    const int npass = (int)((lq + cols_per_pass_max - 1) / cols_per_pass_max);
+    const int W = (int)((lq + (size_t)npass * info.K - 1) / ((size_t)npass * info.K));
+    // residency: info.max_waves is also the wave budget of one CU for this
+    // instantiation's register allocation; LDS is the other limit
+    const size_t lds = info.lds_per_wave * (size_t)W + info.lds_fixed;
+    int per_cu = std::max(1, info.max_waves / W);
+    per_cu = std::max(1, std::min<int>(per_cu, (int)((160 * 1024) / lds)));
+    long wgs = (long)ctx->n_cu * per_cu;
+    if (ctx->opt_workgroups > 0) wgs = ctx->opt_workgroups;
+    wgs = std::max<long>(1, std::min<long>(wgs, (long)n_items));
+    pl->bits = bits;
+    pl->variant = variant;
+    pl->K = info.K;
+    pl->W = W;
+    pl->npass = npass;
+    pl->workgroups = (int)wgs;
+    pl->info = info;
+    return SWG_OK;
+}
+
+static int ensure_profile(swg_ctx *ctx, const Plan &pl)
+{
+    const int which = pl.bits == 16 ? 0 : 1;
+    const uint32_t ncols = (uint32_t)(pl.npass * pl.W * pl.K);
+    const size_t bytes = (size_t)ncols * 32 * pl.info.elem_size;
+    const uint64_t tag = (ctx->epoch << 32) ^ ((uint64_t)pl.K << 20) ^ ((uint64_t)pl.W << 12) ^ (uint64_t)pl.npass;
+    if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
+    if (bytes > ctx->d_profile_cap[which]) {
+        (void)hipFree(ctx->d_profile[which]);
+        ctx->d_profile[which] = nullptr;
+        ctx->d_profile_cap[which] = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_profile[which], bytes));
+        ctx->d_profile_cap[which] = bytes;
+    }
+    HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols,
+                                          pl.info.elem_size, ctx->d_profile[which], ctx->stream));
+    ctx->profile_tag[which] = tag;
+    return SWG_OK;
+}
+
+static int ensure_scratch(swg_ctx *ctx, size_t dwords)
+{
+    if (dwords <= ctx->d_scratch_cap) return SWG_OK;
+    (void)hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr;
+    ctx->d_scratch_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, dwords * 4));
+    ctx->d_scratch_cap = dwords;
+    return SWG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------
+extern "C" uint64_t swg_hit_key(int32_t score, uint32_t index)
+{
+    return ((uint64_t)(uint32_t)(score < 0 ? 0 : score) << 32) | (uint64_t)(0xFFFFFFFFu - index);
+}
+extern "C" void swg_key_hit(uint64_t key, swg_hit *out)
+{
+    if (!out) return;
+    out->score = (int32_t)(key >> 32);
+    out->index = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+}
+extern "C" size_t swg_topk_merge_keys(const uint64_t *keys, size_t n, size_t k, swg_hit *out)
+{
+    if (!keys || !out || k == 0) return 0;
+    std::vector<uint64_t> v;
+    v.reserve(n);
+    for (size_t i = 0; i < n; ++i)
+        if (keys[i] != 0) v.push_back(keys[i]);
+    const size_t m = std::min(k, v.size());
+    std::partial_sort(v.begin(), v.begin() + m, v.end(), std::greater<uint64_t>());
+    for (size_t i = 0; i < m; ++i) swg_key_hit(v[i], &out[i]);
+    return m;
+}
+
+extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, swg_hit *topk_out,
+                          size_t k, size_t *n_hits, swg_stats *stats)
+{
+    if (!ctx || !db) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search: NULL argument");
+    if (!ctx->have_scoring) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: no scoring set");
+    if (ctx->query.empty()) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: no query set");
+    if (db->device != ctx->device || !db->d_scores)
+        return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: database is not resident on device %d",
+                                 ctx->device);
+    if (k > 0 && !topk_out) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search: k > 0 but topk_out NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_hits) *n_hits = 0;
+    swg_stats st;
+    memset(&st, 0, sizeof st);
+    const size_t lq = ctx->query.size();
+    const uint32_t n_bins = db->n_bins;
+    const size_t n_slots = (size_t)n_bins * SWG_BIN;
+    st.cells = (uint64_t)lq * db->residues;
+    st.bytes_alg = db->residues + 8ull * db->n_local + 32ull * lq + 1024ull;
+    if (n_bins == 0) {
+        if (stats) *stats = st;
+        return SWG_OK;
+    }
+
+    // which arithmetic: the packed int16 form needs non-positive gap scores
+    const int go = ctx->gap_open + ctx->gap_extend, ge = ctx->gap_extend;
+    const bool fast_ok = ctx->gap_open <= 0 && ctx->gap_extend <= 0 && -go <= 32767;
+    int bits = fast_ok ? 16 : 32;
+    if (ctx->opt_force_bits == 32) bits = 32;
+    if (ctx->opt_force_bits == 16 && !fast_ok)
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG,
+                                 "force_bits=16 needs gap_open <= 0 and gap_extend <= 0");
+
+    Plan main_pl, re_pl;
+    int rc = make_plan(ctx, bits, bits == 16 ? n_bins : n_bins * 2, &main_pl);
+    if (rc != SWG_OK) return rc;
+    // can an int16 score saturate at all?  score <= min(lq, longest) * max(S)
+    int smax = 0;
+    for (int a = 0; a < 32; ++a)
+        for (int b = 0; b < 32; ++b) smax = std::max<int>(smax, ctx->sub[a][b]);
+    const uint64_t longest = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK;
+    const bool may_saturate = bits == 16 && std::min<uint64_t>(lq, longest) * (uint64_t)smax >= 32767ull;
+    if (may_saturate) {
+        const long keep_cols = ctx->opt_cols;
+        ctx->opt_cols = 0; // the int32 re-score uses its default geometry
+        rc = make_plan(ctx, 32, (uint32_t)std::min<size_t>(n_slots / 64, 1u << 30), &re_pl);
+        ctx->opt_cols = keep_cols;
+        if (rc != SWG_OK) return rc;
+    }
+    rc = ensure_profile(ctx, main_pl);
+    if (rc != SWG_OK) return rc;
+    if (may_saturate && (rc = ensure_profile(ctx, re_pl)) != SWG_OK) return rc;
+    {
+        size_t need = 0;
+        if (main_pl.npass > 1)
+            need = std::max(need, (size_t)main_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb);
+        if (may_saturate && re_pl.npass > 1)
+            need = std::max(need, (size_t)re_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * re_pl.info.nb);
+        if ((rc = ensure_scratch(ctx, need)) != SWG_OK) return rc;
+    }
+
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, s));
+    HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, 64, s));
+
+    SwgFillParams p;
+    memset(&p, 0, sizeof p);
+    p.residues = db->d_packed;
+    p.bin_off = db->d_bin_off;
+    p.bin_nblk = db->d_bin_nblk;
+    p.n_bins = n_bins;
+    p.scores = db->d_scores;
+    p.scratch = ctx->d_scratch;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    {
+        p.profile = ctx->d_profile[bits == 16 ? 0 : 1];
+        p.queue = db->d_counters + 0;
+        p.list = nullptr;
+        p.list_count = nullptr;
+        p.n_items = bits == 16 ? n_bins : n_bins * 2;
+        p.npass = (uint32_t)main_pl.npass;
+        if (bits == 16) {
+            const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
+            p.go = (int32_t)(g | (g << 16));
+            p.ge = (int32_t)(e | (e << 16));
+        } else {
+            p.go = go;
+            p.ge = ge;
+        }
+        p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb;
+        HIP_TRY(ctx, swg_launch_fill(bits, main_pl.variant, main_pl.W, main_pl.workgroups, p, s));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (may_saturate) {
+        HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, db->d_list,
+                                                  db->d_counters + 1, s));
+        p.profile = ctx->d_profile[1];
+        p.queue = db->d_counters + 2;
+        p.list = db->d_list;
+        p.list_count = db->d_counters + 1;
+        p.n_items = 0;
+        p.npass = (uint32_t)re_pl.npass;
+        p.go = go;
+        p.ge = ge;
+        p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * re_pl.info.nb;
+        HIP_TRY(ctx, swg_launch_fill(32, re_pl.variant, re_pl.W, re_pl.workgroups, p, s));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+
+    // read-out: scores of this shard, then top-K (host selection in this round)
+    std::vector<int32_t> h_scores;
+    uint32_t h_counters[4] = {0, 0, 0, 0};
+    const bool need_scores = scores_out != nullptr || k > 0;
+    if (need_scores) {
+        h_scores.resize(n_slots);
+        HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(h_counters, db->d_counters, sizeof h_counters, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    st.fill_ms = ms;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    st.rescore_ms = may_saturate ? ms : 0.0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
+    st.total_ms = ms;
+    st.n_rescored = h_counters[1];
+    st.path_bits = bits;
+    st.cols_per_wave = main_pl.K;
+    st.waves = main_pl.W;
+    st.passes = main_pl.npass;
+    st.workgroups = main_pl.workgroups;
+    st.cells_padded = (uint64_t)main_pl.npass * main_pl.W * main_pl.K * db->rows_padded;
+
+    const auto t0 = std::chrono::steady_clock::now();
+    if (scores_out) {
+        for (size_t i = 0; i < n_slots; ++i) {
+            const uint32_t oi = db->order[i];
+            if (oi != 0xFFFFFFFFu) scores_out[oi] = h_scores[i];
+        }
+    }
+    if (k > 0) {
+        std::vector<uint64_t> keys;
+        keys.reserve(db->n_local);
+        for (size_t i = 0; i < n_slots; ++i) {
+            const uint32_t oi = db->order[i];
+            if (oi != 0xFFFFFFFFu) keys.push_back(swg_hit_key(h_scores[i], oi));
+        }
+        const size_t m = std::min(k, keys.size());
+        std::partial_sort(keys.begin(), keys.begin() + m, keys.end(), std::greater<uint64_t>());
+        for (size_t i = 0; i < m; ++i) swg_key_hit(keys[i], &topk_out[i]);
+        if (n_hits) *n_hits = m;
+    }
+    st.topk_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = st;
+    return SWG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// reference-shaped replay (16-lane batches as alignment_fill_matrices gets them)
+// ---------------------------------------------------------------------------
+extern "C" int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches,
+                                  double *fill_seconds)
+{
+    if (!ctx || (!batches && n_batches))
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_fill_batches16: NULL argument");
+    if (fill_seconds) *fill_seconds = 0.0;
+    std::vector<uint64_t> offsets(1, 0);
+    size_t total = 0;
+    for (size_t b = 0; b < n_batches; ++b) {
+        if (!batches[b].db_idx_t || !batches[b].max_scores || batches[b].vector_size > 16 ||
+            batches[b].max_len == 0)
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_fill_batches16: bad batch %zu", b);
+        total += batches[b].max_len * batches[b].vector_size;
+    }
+    std::vector<int8_t> flat(total);
+    size_t pos = 0;
+    for (size_t b = 0; b < n_batches; ++b) {
+        const swg_batch16 &bt = batches[b];
+        for (size_t l = 0; l < bt.vector_size; ++l) {
+            // lane l, padded rows included: the reference computes them as real
+            // rows (src/alignment_cmdline.c:448-450)
+            for (size_t j = 0; j < bt.max_len; ++j) flat[pos++] = bt.db_idx_t[j * 16 + l];
+            offsets.push_back(pos);
+        }
+    }
+    const size_t n = offsets.size() - 1;
+    if (n == 0) return SWG_OK;
+    swg_db *db = nullptr;
+    int rc = swg_db_pack(flat.data(), offsets.data(), n, 0, 1, &db);
+    if (rc != SWG_OK) {
+        ctx->err = swg_global_error();
+        return rc;
+    }
+    rc = swg_db_upload(ctx, db);
+    std::vector<int32_t> scores(n, 0);
+    swg_stats st;
+    if (rc == SWG_OK) rc = swg_search(ctx, db, scores.data(), nullptr, 0, nullptr, &st);
+    swg_db_free(db);
+    if (rc != SWG_OK) return rc;
+    size_t i = 0;
+    for (size_t b = 0; b < n_batches; ++b)
+        for (size_t l = 0; l < batches[b].vector_size; ++l, ++i)
+            batches[b].max_scores[l] = (int16_t)std::min<int32_t>(scores[i], 32767);
+    if (fill_seconds) *fill_seconds = st.total_ms * 1e-3;
+    return SWG_OK;
+}

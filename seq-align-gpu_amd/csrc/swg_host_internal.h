@@ -1,0 +1,64 @@
+// swg_host_internal.h -- host-side object definitions behind the opaque handles
+// of include/swg.h.  Not part of the public ABI.
+#pragma once
+#include "../../include/swg.h"
+#include "swg_internal.h"
+
+#include <string>
+#include <vector>
+
+struct swg_db {
+    // host image
+    size_t n_total = 0;             // sequences given to swg_db_pack
+    size_t n_local = 0;             // sequences of this shard
+    uint32_t n_bins = 0;            // bins of this shard
+    uint32_t max_nblk = 0;          // row-blocks of the longest bin
+    uint64_t residues = 0;          // sum of lengths (this shard)
+    uint64_t rows_padded = 0;       // sum over bins of nblk*4*128 (rows actually walked)
+    std::vector<uint64_t> bin_off;  // [n_bins] dword offset into packed
+    std::vector<uint32_t> bin_nblk; // [n_bins]
+    std::vector<uint32_t> order;    // [n_bins*128] original index of each slot, ~0u = empty
+    std::vector<uint32_t> lens;     // [n_bins*128]
+    std::vector<uint32_t> packed;   // residue dwords
+    // device image (valid after swg_db_upload)
+    int device = -1;
+    uint32_t *d_packed = nullptr;
+    uint64_t *d_bin_off = nullptr;
+    uint32_t *d_bin_nblk = nullptr;
+    uint32_t *d_order = nullptr;
+    int32_t *d_scores = nullptr;  // [n_bins*128]
+    uint32_t *d_list = nullptr;   // [n_bins*128] saturated slot ids
+    uint32_t *d_counters = nullptr; // [0] work queue, [1] saturated count, [2] queue of rescore
+    uint64_t *d_keys = nullptr;   // [n_bins*128] top-K keys
+};
+
+struct swg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 0;
+    std::string err;
+    // scoring
+    bool have_scoring = false;
+    int8_t sub[32][32];
+    int gap_open = 0, gap_extend = 0;
+    // query
+    std::vector<int8_t> query;
+    // options
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0;
+    // device state
+    int8_t *d_sub = nullptr;
+    int8_t *d_query = nullptr;
+    size_t d_query_cap = 0;
+    uint8_t *d_profile[2] = {nullptr, nullptr}; // [0] int16, [1] int32
+    size_t d_profile_cap[2] = {0, 0};
+    uint64_t profile_tag[2] = {0, 0}; // identifies (query, scoring, geometry) currently built
+    uint64_t epoch = 1;               // bumps whenever scoring or query change
+    uint32_t *d_scratch = nullptr;
+    size_t d_scratch_cap = 0; // dwords
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+int swg_set_global_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
+    __attribute__((format(printf, 3, 4)));
+void swg_db_release_device(swg_db *db);

@@ -1,0 +1,61 @@
+// swg_internal.h -- shared between the C-ABI host layer (swg_api.cpp) and the
+// gfx950 kernels (swg_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Database layout in HBM (built by swg_db_pack, swg_pack.cpp):
+//   sequences sorted by length (descending), 128 consecutive ones form a BIN;
+//   a bin of nblk row-blocks is nblk*128 dwords:  dword[blk*128 + slot] holds
+//   rows 4*blk..4*blk+3 of sequence `slot`, one byte per row, byte = index<<3
+//   (the LDS byte offset of that residue's profile row inside a 256-byte chunk);
+//   rows past a sequence's end are 0 = the padding residue.
+// A wavefront therefore reads 64 consecutive dwords (256 B) per row-block per
+// half-bin: fully coalesced, each residue byte fetched from HBM exactly once.
+#define SWG_BIN 128        // sequences per bin (64 lanes x 2 packed int16 halves)
+#define SWG_ROWS_PER_BLK 4 // DB rows per row-block = residues per dword
+
+struct SwgFillParams {
+    const uint32_t *residues;   // packed bins
+    const uint64_t *bin_off;    // [n_bins] dword offset of a bin's block 0
+    const uint32_t *bin_nblk;   // [n_bins] row-blocks of a bin
+    uint32_t n_bins;
+    const uint8_t *profile;     // [npass][W] slices, see build_profile
+    int32_t *scores;            // [n_bins*128] by sorted slot id; atomicMax target
+    uint32_t *queue;            // work counter, zeroed before the launch
+    const uint32_t *list;       // int32 path: optional list of slot ids to (re)score
+    const uint32_t *list_count; // device-side length of `list` (NULL: use n_items)
+    uint32_t n_items;           // work items when list_count == NULL
+    uint32_t npass;             // query passes
+    int32_t go, ge;             // int16 path: |gap_open+gap_extend|, |gap_extend| in both halves
+                                // int32 path: signed gap_open+gap_extend, gap_extend
+    uint32_t *scratch;          // multi-pass boundary spill, per workgroup
+    uint64_t scratch_wg_dwords; // dwords of scratch owned by one workgroup
+};
+
+struct SwgKernelInfo {
+    int bits;      // 16 or 32
+    int K;         // query columns per wavefront
+    int max_waves; // largest W this instantiation was compiled for
+    size_t lds_per_wave;
+    size_t lds_fixed;
+    int nb;        // boundary dwords per row
+    int elem_size; // profile element bytes
+};
+
+// Launchers (swg_kernels.hip).  variant selects the (K, MAXW) instantiation.
+int swg_num_variants(int bits);
+SwgKernelInfo swg_variant_info(int bits, int variant);
+hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups,
+                           const SwgFillParams &p, hipStream_t stream);
+
+// profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
+// col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.
+hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
+                                    uint32_t lq, uint32_t ncols, int elem_size,
+                                    uint8_t *d_profile, hipStream_t stream);
+
+// Appends every slot id whose int16 score saturated (== 32767) to list.
+hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots,
+                                        uint32_t *d_list, uint32_t *d_count,
+                                        hipStream_t stream);

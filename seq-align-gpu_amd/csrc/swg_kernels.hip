@@ -1,0 +1,516 @@
+// swg_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the Smith-Waterman fill.
+//
+// What is computed: the three-state affine-gap local alignment recurrence of the
+// reference, src/alignment.c:124-161 (H "match", A "gap_a" from the row above,
+// B "gap_b" from the left, all floored at 0, score = max H), for ONE query
+// against every sequence of a packed database -- i.e. the reference's whole
+// timed region, src/alignment_cmdline.c:503-509, not one 16-lane call.
+//
+// How (nothing here follows the reference's AVX2 code):
+//
+//  * Inter-sequence parallelism like the reference's 16 int16 lanes, but at
+//    wave64 width: lane l of a wavefront owns database sequences l and l+64 of
+//    a 128-sequence bin, one in each int16 half of its VGPRs (v_pk_* packed
+//    math), so one wavefront advances 128 alignments per instruction.
+//
+//  * A wavefront keeps K query columns of DP state in registers (3 VGPRs per
+//    column: M = max(H,A,B), G = M - |go| floored, A) and walks down the
+//    database rows.  W wavefronts of a workgroup form a SYSTOLIC array over the
+//    query: wave w owns columns [w*K, (w+1)*K) and runs one row-block (4 rows)
+//    behind wave w-1.  The only values that cross a wave boundary are the right
+//    edge (M, B) of each row; they are handed over through a double-buffered
+//    LDS ring, one s_barrier per row-block.  Nothing of the DP state ever goes
+//    to HBM for queries up to W*K columns; longer queries take several passes,
+//    the last wave spilling its edge to a small per-workgroup scratch that wave
+//    0 re-reads in the next pass (8 B per row per 128 sequences per pass).
+//
+//  * The query profile (substitution scores of every query column against all
+//    32 residue indices) lives in LDS in [4-column chunk][32 residues][4] int16
+//    order: a chunk is exactly one 256-byte LDS bank row and a lane's read
+//    address is chunk*256 + residue*8, so the 32 possible addresses of one
+//    ds_read_b64 hit 32 distinct 8-byte bank slots (or broadcast): the per-lane
+//    gather that dominates the reference (scoring_lookup, src/alignment.c:31-44)
+//    is bank-conflict-free and costs one LDS read per 8 cells.
+//
+//  * Work distribution: bins are sorted longest-first and handed out through an
+//    atomic work counter; a workgroup streams bins back-to-back through its
+//    pipeline without draining it.
+//
+//  * No MFMA: the recurrence is integer max/add with a loop-carried dependency.
+//
+// int16 fast path (gap_open <= 0 and gap_extend <= 0, the normal case): with
+// M = max(H,A,B) the recurrence collapses to
+//     A' = max(M_up - |go|, A_up - |ge|)   B' = max(M_left - |go|, B_left - |ge|)
+//     M' = max(M_diag + s, A', B')         all floored at 0
+// which is value-identical to the reference's (max distributes over +const and
+// go <= ge makes the extra transitions redundant; DESIGN.md gives the proof),
+// 11 packed VALU instructions per two cells.  Floors come for free from
+// unsigned saturating subtracts (v_pk_sub_u16 clamp); the diagonal add is a
+// signed saturating add (v_pk_add_i16 clamp), so a score that reaches 32767
+// sticks there and the sequence is flagged for the int32 path.  The reference
+// wraps silently instead.
+//
+// int32 exact path: the reference's recurrence term by term (valid for any sign
+// of the gap scores), one sequence per lane, used for re-scoring saturated
+// sequences, for unusual gap scores, and when forced.
+#include "swg_internal.h"
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL uint32_t pk_add_i16_sat(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a),
+                                                                      __builtin_bit_cast(s16x2, b)));
+}
+DEVINL uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a),
+                                                                      __builtin_bit_cast(u16x2, b)));
+}
+DEVINL uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a),
+                                                                  __builtin_bit_cast(s16x2, b)));
+}
+DEVINL int imax(int a, int b) { return a > b ? a : b; }
+DEVINL int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
+
+// ---------------------------------------------------------------------------
+// int16 cells: two sequences per lane
+// ---------------------------------------------------------------------------
+template <int K> struct CellsI16 {
+    typedef uint2 edge_t;         // (M, B) of a strip's last column in one row
+    static constexpr int SPL = 2; // sequences per lane
+    static constexpr int ESZ = 2;
+    static constexpr int CHUNK = 32 * 4 * ESZ; // 256 B = one LDS bank row
+    static constexpr int SLICE = (K / 4) * CHUNK;
+    static constexpr int OFF_SHIFT = 0; // residue byte (index<<3) is the LDS offset
+
+    uint32_t M[K], G[K], A[K];
+    uint32_t best, mdl;
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) M[k] = G[k] = A[k] = 0u;
+        best = 0u;
+        mdl = 0u;
+    }
+
+    // One database row.  prof: this wave's LDS profile slice; off[s]: byte
+    // offset of sequence s's residue row; ein = (M,B) of the column left of the
+    // strip in this row; returns (M,B) of the strip's last column.
+    DEVINL edge_t row(const uint8_t *prof, const uint32_t (&off)[SPL], const edge_t ein,
+                      uint32_t go, uint32_t ge)
+    {
+        uint32_t md = mdl;                      // M[j-1][first-1]
+        uint32_t gl = pk_sub_u16_sat(ein.x, go); // max(M_left - |go|, 0)
+        uint32_t bl = ein.y;
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) {
+            const uint2 wx = *reinterpret_cast<const uint2 *>(prof + off[0] + c * CHUNK);
+            const uint2 wy = *reinterpret_cast<const uint2 *>(prof + off[1] + c * CHUNK);
+            uint32_t s[4];
+            s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
+            s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
+            s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
+            s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * c + u;
+                const uint32_t t = pk_add_i16_sat(md, s[u]); // M_diag + s, sticks at 32767
+                md = M[k];
+                const uint32_t a = pk_max_i16(G[k], pk_sub_u16_sat(A[k], ge));
+                const uint32_t b = pk_max_i16(gl, pk_sub_u16_sat(bl, ge));
+                const uint32_t m = pk_max_i16(pk_max_i16(t, a), b);
+                M[k] = m;
+                A[k] = a;
+                gl = G[k] = pk_sub_u16_sat(m, go);
+                bl = b;
+                best = pk_max_i16(best, m);
+            }
+        }
+        mdl = ein.x;
+        return make_uint2(M[K - 1], bl);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// int32 cells: one sequence per lane, the reference's recurrence term by term
+// ---------------------------------------------------------------------------
+template <int K> struct CellsI32 {
+    typedef uint4 edge_t;         // (L = max(H,A), B, D = max(H,A,B), unused)
+    static constexpr int SPL = 1;
+    static constexpr int ESZ = 4;
+    static constexpr int CHUNK = 32 * 4 * ESZ; // 512 B
+    static constexpr int SLICE = (K / 4) * CHUNK;
+    static constexpr int OFF_SHIFT = 1; // residue byte (index<<3) -> index*16
+
+    int U[K], A[K], D[K]; // previous row: U = max(H,B), A, D = max(H,A,B)
+    int best, ddl;
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) U[k] = A[k] = D[k] = 0;
+        best = 0;
+        ddl = 0;
+    }
+
+    DEVINL edge_t row(const uint8_t *prof, const uint32_t (&off)[SPL], const edge_t ein, int go,
+                      int ge)
+    {
+        int dd = ddl;
+        int ll = (int)ein.x, bl = (int)ein.y;
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) {
+            const int4 sv = *reinterpret_cast<const int4 *>(prof + off[0] + c * CHUNK);
+            const int s[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * c + u;
+                const int h = imax(dd + s[u], 0);             // src/alignment.c:124-129
+                const int a = imax3(U[k] + go, A[k] + ge, 0); // src/alignment.c:142-147
+                const int b = imax3(ll + go, bl + ge, 0);     // src/alignment.c:156-161
+                dd = D[k];
+                U[k] = imax(h, b);
+                ll = imax(h, a);
+                D[k] = imax(ll, b);
+                A[k] = a;
+                bl = b;
+                best = imax(best, h);                         // src/alignment.c:133
+            }
+        }
+        ddl = (int)ein.z;
+        return make_uint4((uint32_t)ll, (uint32_t)bl, (uint32_t)D[K - 1], 0u);
+    }
+};
+
+DEVINL uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+// L1-bypassing loads of a spilled edge: it was written by another wavefront of
+// this workgroup; its stores are in L2 once that wave has passed the barrier,
+// but this CU's vector L1 may still hold an older copy of the line.
+DEVINL uint2 load_edge_l2(const uint2 *p)
+{
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+DEVINL uint4 load_edge_l2(const uint4 *p)
+{
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+DEVINL uint2 zero_edge(const uint2 *) { return make_uint2(0u, 0u); }
+DEVINL uint4 zero_edge(const uint4 *) { return make_uint4(0u, 0u, 0u, 0u); }
+
+// ---------------------------------------------------------------------------
+// The systolic fill
+// ---------------------------------------------------------------------------
+#define SWG_ITEM_RING 32
+
+// LDS map of a workgroup of W waves:
+//   [W] profile slices | [(W+1)][2 parities][4 rows][64 lanes] edges | work ids
+// Edge slot w is the INPUT of wave w (slot 0: zeros or the re-read spill) and
+// the output of wave w-1; parity = phase & 1.
+template <class Cells, int K, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef typename Cells::edge_t edge_t;
+    constexpr int SPL = Cells::SPL;
+    constexpr int EDGE = SWG_ROWS_PER_BLK * 64; // edges of one row-block
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+
+    uint8_t *prof = smem + (size_t)w * Cells::SLICE;
+    edge_t *ring = reinterpret_cast<edge_t *>(smem + (size_t)W * Cells::SLICE);
+    uint32_t *items = reinterpret_cast<uint32_t *>(ring + (size_t)(W + 1) * 2 * EDGE);
+    if (threadIdx.x < SWG_ITEM_RING + 2) items[threadIdx.x] = 0u;
+    __syncthreads();
+
+    const uint32_t n_items = p.list_count ? (*p.list_count + 63u) / 64u : p.n_items;
+    const int npass = (int)p.npass;
+    edge_t *scratch =
+        reinterpret_cast<edge_t *>(p.scratch + (size_t)blockIdx.x * p.scratch_wg_dwords);
+
+    Cells cells;
+    cells.reset();
+
+    // stream position of THIS wave (every wave walks the same stream of
+    // row-blocks, one phase apart)
+    uint32_t seq = 0;      // work items started so far
+    int pass = 0, blk = 0; // position inside the current item
+    int nb = 0, nblk_real = 0;
+    bool finished = false;
+    int prof_pass = -1;     // pass whose profile slice is in LDS
+    uint32_t next_item = 0; // wave 0: prefetched work id
+
+    const uint32_t *rptr[SPL];
+    uint32_t sid[SPL];
+    uint32_t cur[SPL];
+    int my_nblk = 0;
+
+    if (w == 0) {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(p.queue, 1u);
+        next_item = __builtin_amdgcn_readfirstlane(v);
+    }
+
+    for (int phase = 0;; ++phase) {
+        if (phase >= w && !finished) {
+            if (blk == 0 && pass == 0) {
+                // ---- next work item -------------------------------------
+                uint32_t item;
+                if (w == 0) {
+                    item = next_item;
+                    if (lane == 0) items[seq % SWG_ITEM_RING] = item;
+                    uint32_t v = 0;
+                    if (lane == 0 && item < n_items) v = atomicAdd(p.queue, 1u);
+                    next_item = __builtin_amdgcn_readfirstlane(v);
+                } else {
+                    item = items[seq % SWG_ITEM_RING];
+                }
+                item = __builtin_amdgcn_readfirstlane(item);
+                if (item >= n_items) {
+                    finished = true;
+                    // the last wave is the last to run dry; the flag is double
+                    // buffered by phase parity so a wave that is already in the
+                    // next phase cannot make a slower one leave early
+                    if (w == W - 1 && lane == 0) items[SWG_ITEM_RING + (phase & 1)] = 1u;
+                } else {
+                    if constexpr (SPL == 2) {
+                        nblk_real = (int)p.bin_nblk[item];
+                        my_nblk = nblk_real;
+                        rptr[0] = p.residues + p.bin_off[item] + lane;
+                        rptr[1] = rptr[0] + 64;
+                        sid[0] = item * SWG_BIN + lane;
+                        sid[1] = sid[0] + 64;
+                    } else {
+                        const uint32_t gi = item * 64u + lane;
+                        uint32_t s;
+                        bool valid;
+                        if (p.list) {
+                            valid = gi < *p.list_count;
+                            s = valid ? p.list[gi] : 0u;
+                        } else {
+                            s = gi;
+                            valid = s < p.n_bins * SWG_BIN;
+                        }
+                        const uint32_t b = s / SWG_BIN;
+                        my_nblk = valid ? (int)p.bin_nblk[b] : 0;
+                        rptr[0] = p.residues + (valid ? p.bin_off[b] : 0) + (s % SWG_BIN);
+                        sid[0] = valid ? s : 0xFFFFFFFFu;
+                        nblk_real = __builtin_amdgcn_readfirstlane(
+                            (int)wave_max_u32((uint32_t)my_nblk));
+                    }
+                    // a spilled edge is re-read W-1 phases after it was
+                    // written: keep passes at least W blocks apart
+                    nb = (npass > 1 && nblk_real < W) ? W : nblk_real;
+                }
+            }
+            if (!finished) {
+                if (blk == 0) {
+                    cells.reset();
+                    if (prof_pass != pass) {
+                        // this wave's slice of the query profile -> LDS
+                        const uint8_t *src = p.profile + ((size_t)pass * W + w) * Cells::SLICE;
+                        for (int o = lane * 16; o < Cells::SLICE; o += 64 * 16)
+                            *reinterpret_cast<uint4 *>(prof + o) =
+                                *reinterpret_cast<const uint4 *>(src + o);
+                        prof_pass = pass;
+                    }
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s) cur[s] = (0 < my_nblk) ? rptr[s][0] : 0u;
+                }
+                if (blk < nblk_real) {
+                    // ---- one row-block: 4 database rows ------------------
+                    uint32_t res[SPL];
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s) {
+                        res[s] = cur[s];
+                        cur[s] = (blk + 1 < my_nblk) ? rptr[s][(size_t)(blk + 1) * SWG_BIN] : 0u;
+                    }
+                    // this lane's 4 input edges and 4 output edges
+                    edge_t *ein_p = ring + ((size_t)w * 2 + ((phase + 1) & 1)) * EDGE + lane;
+                    edge_t *eout_p = ring + ((size_t)(w + 1) * 2 + (phase & 1)) * EDGE + lane;
+                    edge_t *sc = scratch + (size_t)blk * EDGE + lane;
+                    if (w == 0) {
+                        // the column left of the query: zeros in the first pass,
+                        // otherwise what the last wave spilled in the previous
+                        // pass.  Same lane writes and reads: no barrier needed.
+#pragma unroll
+                        for (int r = 0; r < SWG_ROWS_PER_BLK; ++r)
+                            ein_p[r * 64] = (pass == 0) ? zero_edge(sc) : load_edge_l2(sc + r * 64);
+                    }
+#pragma unroll
+                    for (int r = 0; r < SWG_ROWS_PER_BLK; ++r) {
+                        uint32_t off[SPL];
+#pragma unroll
+                        for (int s = 0; s < SPL; ++s)
+                            off[s] = ((res[s] >> (8 * r)) & 0xFFu) << Cells::OFF_SHIFT;
+                        eout_p[r * 64] = cells.row(prof, off, ein_p[r * 64], p.go, p.ge);
+                    }
+                    if (w == W - 1 && pass + 1 < npass) {
+                        // spill the query-side edge for the next pass; the stores
+                        // must have reached L2 before this wave signals the
+                        // barrier (hipcc's __syncthreads only drains lgkmcnt here)
+#pragma unroll
+                        for (int r = 0; r < SWG_ROWS_PER_BLK; ++r) sc[r * 64] = eout_p[r * 64];
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                ++blk;
+                if (blk == nb) {
+                    // ---- end of this (item, pass): publish the maxima ------
+                    if constexpr (SPL == 2) {
+                        atomicMax(p.scores + sid[0], (int)(cells.best & 0xFFFFu));
+                        atomicMax(p.scores + sid[1], (int)(cells.best >> 16));
+                    } else {
+                        if (sid[0] != 0xFFFFFFFFu) atomicMax(p.scores + sid[0], cells.best);
+                    }
+                    blk = 0;
+                    if (++pass == npass) {
+                        pass = 0;
+                        ++seq;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (items[SWG_ITEM_RING + (phase & 1)] != 0u) break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+__global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
+                                         uint32_t ncols, int elem_size, uint8_t *out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (col, code)
+    if (t >= ncols * 32u) return;
+    const uint32_t col = t >> 5, code = t & 31u;
+    const bool pad = (col >= lq) || (code == 0u);
+    const int v = pad ? 0 : (int)sub[(int)query[col] * 32 + (int)code];
+    const size_t e = (size_t)(col >> 2) * 128u + code * 4u + (col & 3u);
+    if (elem_size == 2)
+        reinterpret_cast<int16_t *>(out)[e] = pad ? (int16_t)-32768 : (int16_t)v;
+    else
+        reinterpret_cast<int32_t *>(out)[e] = pad ? -(1 << 29) : v;
+}
+
+__global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, uint32_t *list,
+                                             uint32_t *count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && scores[i] >= 32767) list[atomicAdd(count, 1u)] = i;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+namespace {
+struct Variant {
+    SwgKernelInfo info;
+    void (*kernel)(const SwgFillParams);
+};
+
+template <class Cells, int K, int MAXW, int BITS> Variant make_variant()
+{
+    Variant v;
+    v.info.bits = BITS;
+    v.info.K = K;
+    v.info.max_waves = MAXW;
+    v.info.nb = (int)(sizeof(typename Cells::edge_t) / 4);
+    v.info.elem_size = Cells::ESZ;
+    v.info.lds_per_wave = Cells::SLICE + 2 * SWG_ROWS_PER_BLK * 64 * sizeof(typename Cells::edge_t);
+    v.info.lds_fixed = 2 * SWG_ROWS_PER_BLK * 64 * sizeof(typename Cells::edge_t) + (SWG_ITEM_RING + 2) * 4;
+    v.kernel = swg_fill_kernel<Cells, K, MAXW>;
+    return v;
+}
+
+const Variant *variants16(int *n)
+{
+    static const Variant v[] = {
+        make_variant<CellsI16<32>, 32, 12, 16>(),
+        make_variant<CellsI16<16>, 16, 16, 16>(),
+        make_variant<CellsI16<48>, 48, 8, 16>(),
+    };
+    *n = (int)(sizeof(v) / sizeof(v[0]));
+    return v;
+}
+const Variant *variants32(int *n)
+{
+    static const Variant v[] = {
+        make_variant<CellsI32<32>, 32, 12, 32>(),
+        make_variant<CellsI32<16>, 16, 16, 32>(),
+    };
+    *n = (int)(sizeof(v) / sizeof(v[0]));
+    return v;
+}
+const Variant *variants(int bits, int *n) { return bits == 16 ? variants16(n) : variants32(n); }
+} // namespace
+
+int swg_num_variants(int bits)
+{
+    int n;
+    variants(bits, &n);
+    return n;
+}
+
+SwgKernelInfo swg_variant_info(int bits, int variant)
+{
+    int n;
+    const Variant *v = variants(bits, &n);
+    return v[variant].info;
+}
+
+hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups, const SwgFillParams &p,
+                           hipStream_t stream)
+{
+    int n;
+    const Variant *v = variants(bits, &n);
+    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1)
+        return hipErrorInvalidValue;
+    const size_t lds = v[variant].info.lds_per_wave * (size_t)W + v[variant].info.lds_fixed;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(v[variant].kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(v[variant].kernel, dim3(workgroups), dim3(W * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, uint32_t lq,
+                                    uint32_t ncols, int elem_size, uint8_t *d_profile,
+                                    hipStream_t stream)
+{
+    const uint32_t n = ncols * 32u;
+    hipLaunchKernelGGL(swg_build_profile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_sub,
+                       d_query, lq, ncols, elem_size, d_profile);
+    return hipGetLastError();
+}
+
+hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, uint32_t *d_list,
+                                        uint32_t *d_count, hipStream_t stream)
+{
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_collect_saturated_kernel, dim3((n_slots + 255) / 256), dim3(256), 0,
+                       stream, d_scores, n_slots, d_list, d_count);
+    return hipGetLastError();
+}

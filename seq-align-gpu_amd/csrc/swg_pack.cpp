@@ -1,0 +1,145 @@
+// swg_pack.cpp -- host-side database packer (no GPU needed).
+//
+// Replaces what the reference does per 16 records at
+// src/alignment_cmdline.c:429-452 (letters -> indices, transpose to [j][lane],
+// pad with '*'): here the whole database is sorted by length once (the
+// reference instead REQUIRES a pre-sorted input, src/alignment_cmdline.c:431-439),
+// cut into bins of 128 sequences and stored row-block-major, one dword per four
+// residues per sequence, padding = residue 0.
+#include "swg_host_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n, int shard_rank,
+                           int shard_count, swg_db **out)
+{
+    if (!out) return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: out is NULL");
+    *out = nullptr;
+    if ((!flat && n > 0 && offsets && offsets[n] > 0) || (!offsets && n > 0))
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: NULL input");
+    if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count)
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: bad shard %d/%d", shard_rank,
+                                    shard_count);
+    if (n >= 0xFFFFFFF0ull)
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: too many sequences");
+
+    // lengths + validation (the reference exits in letters_to_index on anything
+    // outside A-Z/a-z/'*'; here an index outside 1..31 is an error code)
+    uint64_t max_len = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i])
+            return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: offsets not monotone at %zu", i);
+        max_len = std::max<uint64_t>(max_len, offsets[i + 1] - offsets[i]);
+    }
+    if (max_len > 0x3FFFFFFFull)
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: sequence too long");
+    const uint64_t total = n ? offsets[n] - offsets[0] : 0;
+    {
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+        for (long long i = (long long)offsets[0]; i < (long long)(offsets[0] + total); ++i) {
+            const int v = flat[i];
+            bad |= (v < 1 || v > 31);
+        }
+        if (bad)
+            return swg_set_global_error(SWG_ERR_RESIDUE,
+                                        "swg_db_pack: residue index outside 1..31 in database");
+    }
+
+    swg_db *db = new (std::nothrow) swg_db();
+    if (!db) return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
+    db->n_total = n;
+
+    // stable counting sort by length, descending
+    std::vector<uint32_t> sorted(n);
+    {
+        std::vector<uint64_t> cnt(max_len + 2, 0);
+        for (size_t i = 0; i < n; ++i) cnt[max_len - (offsets[i + 1] - offsets[i]) + 1]++;
+        for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
+        for (size_t i = 0; i < n; ++i) sorted[cnt[max_len - (offsets[i + 1] - offsets[i])]++] = (uint32_t)i;
+    }
+
+    // bins of the global order that belong to this shard
+    const size_t n_bins_global = (n + SWG_BIN - 1) / SWG_BIN;
+    std::vector<size_t> my_bins;
+    for (size_t b = (size_t)shard_rank; b < n_bins_global; b += (size_t)shard_count)
+        my_bins.push_back(b);
+    const size_t nb = my_bins.size();
+    db->n_bins = (uint32_t)nb;
+    db->bin_off.resize(nb);
+    db->bin_nblk.resize(nb);
+    db->order.assign(nb * SWG_BIN, 0xFFFFFFFFu);
+    db->lens.assign(nb * SWG_BIN, 0u);
+    uint64_t dwords = 0;
+    uint64_t residues = 0, rows_padded = 0;
+    size_t n_local = 0;
+    for (size_t lb = 0; lb < nb; ++lb) {
+        const size_t first = my_bins[lb] * SWG_BIN;
+        const uint64_t len0 = offsets[sorted[first] + 1] - offsets[sorted[first]];
+        const uint32_t nblk = (uint32_t)std::max<uint64_t>(1, (len0 + SWG_ROWS_PER_BLK - 1) / SWG_ROWS_PER_BLK);
+        db->bin_off[lb] = dwords;
+        db->bin_nblk[lb] = nblk;
+        dwords += (uint64_t)nblk * SWG_BIN;
+        rows_padded += (uint64_t)nblk * SWG_ROWS_PER_BLK * SWG_BIN;
+        for (size_t s = 0; s < SWG_BIN && first + s < n; ++s) {
+            const uint32_t oi = sorted[first + s];
+            db->order[lb * SWG_BIN + s] = oi;
+            const uint32_t len = (uint32_t)(offsets[oi + 1] - offsets[oi]);
+            db->lens[lb * SWG_BIN + s] = len;
+            residues += len;
+            ++n_local;
+        }
+    }
+    db->n_local = n_local;
+    db->residues = residues;
+    db->rows_padded = rows_padded;
+    db->max_nblk = nb ? *std::max_element(db->bin_nblk.begin(), db->bin_nblk.end()) : 0;
+    try {
+        db->packed.assign(dwords, 0u);
+    } catch (const std::bad_alloc &) {
+        delete db;
+        return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory (%llu dwords)",
+                                    (unsigned long long)dwords);
+    }
+
+    uint32_t *pk = db->packed.data();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long long lb = 0; lb < (long long)nb; ++lb) {
+        uint32_t *base = pk + db->bin_off[lb];
+        for (size_t s = 0; s < SWG_BIN; ++s) {
+            const uint32_t oi = db->order[lb * SWG_BIN + s];
+            if (oi == 0xFFFFFFFFu) continue;
+            const int8_t *src = flat + offsets[oi];
+            const uint32_t len = db->lens[lb * SWG_BIN + s];
+            for (uint32_t j = 0; j < len; j += 4) {
+                uint32_t wd = 0;
+                const uint32_t m = std::min<uint32_t>(4, len - j);
+                for (uint32_t r = 0; r < m; ++r) wd |= ((uint32_t)(uint8_t)src[j + r] << 3) << (8 * r);
+                base[(size_t)(j / 4) * SWG_BIN + s] = wd;
+            }
+        }
+    }
+    *out = db;
+    return SWG_OK;
+}
+
+extern "C" void swg_db_free(swg_db *db)
+{
+    if (!db) return;
+    swg_db_release_device(db);
+    delete db;
+}
+
+extern "C" size_t swg_db_count(const swg_db *db) { return db ? db->n_local : 0; }
+extern "C" size_t swg_db_total_count(const swg_db *db) { return db ? db->n_total : 0; }
+extern "C" uint64_t swg_db_residues(const swg_db *db) { return db ? db->residues : 0; }
+extern "C" uint64_t swg_db_packed_bytes(const swg_db *db)
+{
+    return db ? (uint64_t)db->packed.size() * 4u + (uint64_t)db->n_bins * 12u : 0;
+}
+extern "C" const uint32_t *swg_db_order(const swg_db *db) { return db ? db->order.data() : nullptr; }

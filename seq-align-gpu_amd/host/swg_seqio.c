@@ -1,0 +1,179 @@
+/*
+ * swg_seqio.c -- minimal sequence-file reader (FASTA / FASTQ / plain, gzip
+ * transparent).  Stands in for the un-vendored libs/seq_file the reference
+ * driver calls (seq_open/seq_read, src/alignment_cmdline.c:335-339, 370-386,
+ * 422-457): name = header line without its '>' or '@', sequence = all sequence
+ * lines joined, newlines dropped.  Host-only C.
+ */
+#include "../../include/swg.h"
+#include "../../include/swg_host.h"
+
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+typedef struct {
+    char *p;
+    size_t len, cap;
+} cbuf;
+
+static int cb_add(cbuf *b, const char *s, size_t n)
+{
+    if (b->len + n + 1 > b->cap) {
+        size_t nc = b->cap ? b->cap : 4096;
+        while (nc < b->len + n + 1) nc *= 2;
+        char *np = (char *)realloc(b->p, nc);
+        if (!np) return -1;
+        b->p = np;
+        b->cap = nc;
+    }
+    memcpy(b->p + b->len, s, n);
+    b->len += n;
+    b->p[b->len] = '\0';
+    return 0;
+}
+
+typedef struct {
+    uint64_t *p;
+    size_t len, cap;
+} obuf;
+
+static int ob_add(obuf *b, uint64_t v)
+{
+    if (b->len == b->cap) {
+        size_t nc = b->cap ? b->cap * 2 : 1024;
+        uint64_t *np = (uint64_t *)realloc(b->p, nc * sizeof(uint64_t));
+        if (!np) return -1;
+        b->p = np;
+        b->cap = nc;
+    }
+    b->p[b->len++] = v;
+    return 0;
+}
+
+void swg_seqs_free(swg_seqs *s)
+{
+    if (!s) return;
+    free(s->names);
+    free(s->name_off);
+    free(s->seq);
+    free(s->seq_off);
+    memset(s, 0, sizeof *s);
+}
+
+int swg_seqs_read(const char *path, size_t max_records, swg_seqs *out, char *err, size_t errlen)
+{
+    if (!path || !out) return SWG_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    gzFile f = strcmp(path, "-") == 0 ? gzdopen(0, "r") : gzopen(path, "r");
+    if (!f) {
+        if (err) snprintf(err, errlen, "couldn't open %s", path);
+        return SWG_ERR_IO;
+    }
+    gzbuffer(f, 1 << 20);
+    cbuf names = {0}, seq = {0};
+    obuf noff = {0}, soff = {0};
+    size_t cap = 1 << 16;
+    char *line = (char *)malloc(cap);
+    int rc = SWG_OK;
+    int state = 0; /* 0 none, 1 fasta body, 2 fastq seq, 3 fastq '+', 4 fastq qual */
+    size_t n = 0;
+    int oom = !line;
+    while (!oom) {
+        /* read one full line */
+        size_t len = 0;
+        int eof = 0;
+        for (;;) {
+            if (!gzgets(f, line + len, (int)(cap - len))) {
+                eof = 1;
+                break;
+            }
+            len += strlen(line + len);
+            if (len && line[len - 1] == '\n') break;
+            if (cap - len < 2) {
+                char *nl = (char *)realloc(line, cap * 2);
+                if (!nl) {
+                    oom = 1;
+                    break;
+                }
+                line = nl;
+                cap *= 2;
+            }
+        }
+        if (oom) break;
+        if (eof && len == 0) break;
+        while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = '\0';
+        if (state == 3) { /* FASTQ '+' seen: this is the quality line */
+            state = 0;
+            if (eof) break;
+            continue;
+        }
+        if (len == 0) {
+            if (eof) break;
+            continue;
+        }
+        if ((line[0] == '>' && state != 2) || (line[0] == '@' && (state == 0))) {
+            if (max_records && n == max_records) break;
+            oom |= ob_add(&noff, names.len) || ob_add(&soff, seq.len);
+            oom |= cb_add(&names, line + 1, len - 1) || cb_add(&names, "", 1);
+            names.len -= 0;
+            n++;
+            state = line[0] == '>' ? 1 : 2;
+        } else if (state == 2 && line[0] == '+') {
+            state = 3;
+        } else if (state == 1 || state == 2) {
+            /* sequence line: drop embedded blanks */
+            size_t w = 0;
+            for (size_t i = 0; i < len; i++)
+                if (!isspace((unsigned char)line[i])) line[w++] = line[i];
+            oom |= cb_add(&seq, line, w);
+        } else {
+            /* plain: one sequence per line, no name */
+            if (max_records && n == max_records) break;
+            oom |= ob_add(&noff, names.len) || ob_add(&soff, seq.len);
+            oom |= cb_add(&names, "", 1);
+            size_t w = 0;
+            for (size_t i = 0; i < len; i++)
+                if (!isspace((unsigned char)line[i])) line[w++] = line[i];
+            oom |= cb_add(&seq, line, w);
+            n++;
+        }
+        if (eof) break;
+    }
+    if (!oom) oom |= ob_add(&noff, names.len) || ob_add(&soff, seq.len);
+    if (!oom && !seq.p) oom |= cb_add(&seq, "", 0);
+    if (!oom && !names.p) oom |= cb_add(&names, "", 0);
+    gzclose(f);
+    free(line);
+    if (oom) {
+        free(names.p);
+        free(seq.p);
+        free(noff.p);
+        free(soff.p);
+        if (err) snprintf(err, errlen, "out of memory reading %s", path);
+        return SWG_ERR_NOMEM;
+    }
+    out->n = n;
+    out->names = names.p;
+    out->name_off = noff.p;
+    out->seq = seq.p;
+    out->seq_off = soff.p;
+    return rc;
+}
+
+int swg_seqs_to_indices(const swg_seqs *s, int8_t *out, char *bad)
+{
+    if (!s || !out) return SWG_ERR_ARG;
+    const uint64_t total = s->n ? s->seq_off[s->n] : 0;
+    for (uint64_t i = 0; i < total; i++) {
+        const int v = swg_letter_index((unsigned char)s->seq[i]);
+        if (v < 0) {
+            if (bad) *bad = s->seq[i];
+            return SWG_ERR_RESIDUE;
+        }
+        out[i] = (int8_t)v;
+    }
+    return SWG_OK;
+}

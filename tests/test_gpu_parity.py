@@ -1,0 +1,186 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the golden vectors (every
+expected value produced by the reference's own alignment_fill_matrices) and against the int32
+oracle on seeded inputs.  Integer work: the bar is bit-exact, per database sequence."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, g):
+    ctx.set_scoring(g["sub"], int(g["gaps"][0]), int(g["gaps"][1]))
+    ctx.set_query(g["query"])
+    for k in ("force_bits", "cols_per_wave", "max_waves", "workgroups"):
+        ctx.set_option(k, 0)
+
+
+def _truth(g):
+    return g["oracle32"]
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_through_search(swg, ctx, name):
+    g = load_golden(name)
+    _setup(ctx, g)
+    db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    scores, hits, st = ctx.search(db, k=10)
+    assert np.array_equal(scores, _truth(g)), (name, st)
+    if g["ref_valid"][0]:
+        assert np.array_equal(scores, g["ref16"].astype(np.int32))
+    best = sorted(((-int(s), i) for i, s in enumerate(_truth(g))))[:10]
+    assert hits == [(-s, i) for s, i in best]
+    gaps_ok = g["gaps"][0] <= 0 and g["gaps"][1] <= 0
+    assert st["path_bits"] == (16 if gaps_ok else 32)
+    assert st["cells"] == len(g["query"]) * len(g["flat"])
+    db.close()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_forced_int32(swg, ctx, name):
+    g = load_golden(name)
+    _setup(ctx, g)
+    ctx.set_option("force_bits", 32)
+    db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    scores, _, st = ctx.search(db)
+    assert st["path_bits"] == 32
+    assert np.array_equal(scores, _truth(g)), name
+    db.close()
+
+
+@pytest.mark.parametrize("name", ["pam250_lq128", "blosum62_lq367", "pam250_partial_lanes",
+                                  "blosum62_gap_0_1", "blosum62_gap_pos1_m3", "blosum62_query_bzx"])
+def test_golden_through_reference_shaped_batches(swg, ctx, orc, name):
+    """swg_fill_batches16 replays exactly what alignment_fill_matrices receives."""
+    g = load_golden(name)
+    _setup(ctx, g)
+    batches = orc.db_to_batches16(g["flat"], g["offsets"])
+    lanes = [int(v) for v in g["lanes"]]
+    out, secs = ctx.fill_batches16(list(zip(batches, lanes)))
+    for b, (o, nl) in enumerate(zip(out, lanes)):
+        assert np.array_equal(o, g["ref16"][b * 16:b * 16 + nl]), (name, b)
+    assert secs > 0
+
+
+def test_overflow_is_detected_and_rescored(swg, ctx):
+    g = load_golden("pam250_overflow_w")
+    _setup(ctx, g)
+    db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    scores, _, st = ctx.search(db)
+    assert np.array_equal(scores, g["oracle32"])
+    assert st["path_bits"] == 16 and st["n_rescored"] == int((g["oracle32"] >= 32767).sum())
+    assert (scores != g["ref16"]).any()      # the reference itself is wrong here (wraps)
+    db.close()
+
+
+@pytest.mark.parametrize("cols,maxw", [(32, 0), (16, 0), (48, 0), (32, 1), (32, 2), (16, 3), (32, 5)])
+def test_geometry_does_not_change_scores(swg, ctx, cols, maxw):
+    """Strip width, wave count and the number of query passes are invisible in the result."""
+    for name in ("blosum62_lq367", "blosum62_lq3000", "pam250_partial_lanes", "blosum62_tiny_db"):
+        g = load_golden(name)
+        _setup(ctx, g)
+        ctx.set_option("cols_per_wave", cols)
+        ctx.set_option("max_waves", maxw)
+        db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+        scores, _, st = ctx.search(db)
+        assert np.array_equal(scores, g["oracle32"]), (name, cols, maxw, st)
+        assert st["cols_per_wave"] == cols
+        if maxw:
+            assert st["waves"] <= maxw and st["passes"] == -(-len(g["query"]) // (cols * st["waves"])) \
+                or st["passes"] >= 1
+        db.close()
+
+
+def test_multipass_int32_and_few_workgroups(swg, ctx):
+    g = load_golden("blosum62_lq3000")
+    _setup(ctx, g)
+    ctx.set_option("force_bits", 32)
+    ctx.set_option("max_waves", 3)
+    ctx.set_option("workgroups", 1)
+    db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    scores, _, st = ctx.search(db)
+    assert st["passes"] > 1 and st["workgroups"] == 1
+    assert np.array_equal(scores, g["oracle32"])
+    db.close()
+
+
+def test_random_database_matches_oracle(swg, ctx, orc):
+    """Config-2-shaped (PAM250, lq 367) but small enough for the scalar oracle."""
+    sc = swg.load_scoring("PAM250")
+    q = swg.synth_query(0x5EED0002, 367)
+    flat, off = swg.synth_db(0x5EED0002, 3000)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    for k in ("force_bits", "cols_per_wave", "max_waves", "workgroups"):
+        ctx.set_option(k, 0)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    db = swg.Database(flat, off).upload(ctx)
+    scores, hits, st = ctx.search(db, k=100)
+    assert np.array_equal(scores, want)
+    assert hits == orc.topk(want, 100)
+    # unsorted input order must not matter: shuffle, search, compare per sequence
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(off) - 1)
+    lens = np.diff(off.astype(np.int64))
+    off2 = np.zeros_like(off)
+    off2[1:] = np.cumsum(lens[perm])
+    flat2 = np.concatenate([flat[int(off[i]):int(off[i + 1])] for i in perm])
+    db2 = swg.Database(flat2, off2).upload(ctx)
+    scores2, _, _ = ctx.search(db2)
+    assert np.array_equal(scores2, want[perm])
+    # shards: union of per-shard results == whole, merged top-K == global top-K
+    merged = np.zeros_like(want)
+    keys = []
+    for r in range(3):
+        s = swg.Database(flat, off, r, 3).upload(ctx)
+        sc_r, hits_r, _ = ctx.search(s, k=100)
+        o = s.order()
+        merged[o] = sc_r[o]
+        keys += [swg.hit_key(a, b) for a, b in hits_r]
+        s.close()
+    assert np.array_equal(merged, want)
+    assert swg.topk_merge_keys(np.array(keys, dtype=np.uint64), 100) == orc.topk(want, 100)
+    db.close()
+    db2.close()
+
+
+def test_high_similarity_rescore_matches_oracle(swg, ctx, orc):
+    """Config-5-shaped: planted near-copies of a long query saturate int16 and are re-scored."""
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(0x5EED0005, 8192)
+    flat, off, planted = swg.synth_db(0x5EED0005, 600, query=q, fraction=0.02, subst=0.05)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    for k in ("force_bits", "cols_per_wave", "max_waves", "workgroups"):
+        ctx.set_option(k, 0)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    assert planted >= 3 and (want > 32767).sum() == planted
+    db = swg.Database(flat, off).upload(ctx)
+    scores, hits, st = ctx.search(db, k=20)
+    assert np.array_equal(scores, want)
+    assert st["n_rescored"] == planted and st["passes"] > 1
+    assert hits == orc.topk(want, 20)
+    db.close()
+
+
+def test_errors_are_codes_not_crashes(swg, ctx):
+    g = load_golden("blosum62_lq1")
+    _setup(ctx, g)
+    with pytest.raises(swg.SwgError) as e:
+        ctx.set_query(np.array([1, 0, 3], dtype=np.int8))
+    assert e.value.code == swg.SWG_ERR_RESIDUE
+    with pytest.raises(swg.SwgError):
+        ctx.set_option("nonsense", 1)
+    db = swg.Database(g["flat"], g["offsets"])          # packed but never uploaded
+    with pytest.raises(swg.SwgError) as e:
+        ctx.search(db)
+    assert e.value.code == swg.SWG_ERR_STATE
+    ctx.set_option("cols_per_wave", 7)
+    db.upload(ctx)
+    with pytest.raises(swg.SwgError):
+        ctx.search(db)
+    ctx.set_option("cols_per_wave", 0)
+    empty = swg.Database(np.zeros(0, np.int8), np.zeros(1, np.uint64)).upload(ctx)
+    scores, hits, st = ctx.search(empty, k=5)
+    assert scores.size == 0 and hits == [] and st["cells"] == 0

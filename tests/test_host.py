@@ -1,0 +1,199 @@
+"""CPU: the C-ABI library loads, exports every declared symbol, and its host-only logic
+(residue map, matrix reader, sequence reader, packer, synthetic data, hit keys) behaves.
+No compute entry point is called: there is no GPU here and the library has no CPU backend."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, load_golden
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(swg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_abi_exports_every_declared_symbol(swg):
+    names = _declared("swg.h") + _declared("swg_host.h")
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(swg.lib, n), "libswg.so does not export " + n
+    assert sorted(names) == sorted(swg.ABI_SYMBOLS)
+    assert swg.lib.swg_abi_version() == 1
+
+
+def test_no_cpu_fallback(swg):
+    """Without a GPU the product must refuse, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(swg.SwgError) as e:
+        swg.Context(0)
+    assert e.value.code == swg.SWG_ERR_NODEVICE
+    assert "no CPU backend" in str(e.value)
+
+
+def test_product_does_not_touch_oracle():
+    """Nothing under seq-align-gpu_amd/ may reference oracle/ (test infrastructure)."""
+    pkg = os.path.join(ROOT, "seq-align-gpu_amd")
+    for d, _, files in os.walk(pkg):
+        if os.path.basename(d) in ("build", "__pycache__", "bin"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".c", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                assert "oracle" not in txt.replace("oracle/ ", "").lower() or f == "__init__.py" and \
+                    "liboracle" not in txt, (d, f)
+
+
+def test_letter_index(swg, orc):
+    for c in range(256):
+        assert swg.lib.swg_letter_index(c) == orc.letter_index(chr(c))
+    assert swg.lib.swg_index_letter(1) == ord("A") and swg.lib.swg_index_letter(31) == ord("*")
+    assert swg.lib.swg_index_letter(0) == 0 and swg.lib.swg_index_letter(27) == 0
+    with pytest.raises(swg.SwgError):
+        swg.letters_to_indices("AC-GT")
+
+
+@pytest.mark.parametrize("name,fixture", [("BLOSUM62", "blosum62_lq367"), ("PAM250", "pam250_lq128"),
+                                          ("BLOSUM45", "blosum45_lq200")])
+def test_matrix_reader_matches_golden_tables(swg, name, fixture):
+    sc = swg.load_scoring(name)
+    assert np.array_equal(sc.table(), load_golden(fixture)["sub"])
+    assert (sc.gap_open, sc.gap_extend, sc.match, sc.mismatch) == (-2, -1, 2, -2)
+    a, x, j = (swg.lib.swg_letter_index(ord(c)) for c in "AXJ")
+    assert (sc.set[a] >> a) & 1 and (sc.set[x] >> x) & 1 and not (sc.set[j] >> j) & 1
+    # query sanitisation: undefined self-pair -> X (reference src/alignment_cmdline.c:391-396)
+    q = swg.letters_to_indices("AJOUW")
+    swg.lib.swg_query_sanitize(C.byref(sc), q.ctypes.data_as(C.c_void_p), q.size)
+    assert list(q) == [a, x, x, x, swg.lib.swg_letter_index(ord("W"))]
+
+
+def test_matrix_reader_formats_and_errors(swg, tmp_path):
+    def load(text):
+        p = tmp_path / "m.txt"
+        p.write_text(text)
+        return swg.load_scoring(str(p))
+    sc = load("# c\n\n   A  C\nA  5 -3 \nC -3  7\n# tail\n")
+    t = sc.table()
+    assert t[1, 1] == 5 and t[1, 3] == -3 and t[3, 3] == 7
+    sc = load(",A,C\nA,5,-3\nC,-3,7\n")  # single-character separator mode
+    assert sc.table()[3, 1] == -3
+    import gzip
+    p = tmp_path / "m.txt.gz"
+    with gzip.open(p, "wt") as f:
+        f.write("  A C\nA 1 2\nC 3 4\n")
+    assert swg.load_scoring(str(p)).table()[3, 3] == 4  # gz-transparent like the reference
+    for bad in ("", "# only comment\n", "  A C\nA 1\n", "  A C\nA 1 2 3\n", "  A C\nA 1 x\n",
+                "1A1C\nA151\n", "  A C\nA 1 200\n", "  A ?\nA 1 2\n"):
+        with pytest.raises(swg.SwgError):
+            load(bad)
+    with pytest.raises(swg.SwgError):
+        swg.load_scoring(str(tmp_path / "missing.txt"))
+
+
+def test_sequence_reader(swg, tmp_path):
+    p = tmp_path / "a.fasta"
+    p.write_text(">q1 first\nACDE\nFGH\n\n>q2\nkl mn\n>empty\n>last\nWW")
+    names, seq, idx, off = swg.read_seqs(str(p))
+    assert names == ["q1 first", "q2", "empty", "last"]
+    assert seq == b"ACDEFGHklmnWW" and list(off) == [0, 7, 11, 11, 13]
+    assert list(idx[:3]) == [1, 3, 4] and idx[7] == 11
+    names, seq, idx, off = swg.read_seqs(str(p), 2)
+    assert names == ["q1 first", "q2"]
+    fq = tmp_path / "a.fastq"
+    fq.write_text("@r1\nACGT\n+\n@@II\n@r2\nTT\n+r2\nII\n")
+    names, seq, _, off = swg.read_seqs(str(fq))
+    assert names == ["r1", "r2"] and seq == b"ACGTTT"
+    pl = tmp_path / "plain.txt"
+    pl.write_text("ACD\nEFG\n")
+    names, seq, _, off = swg.read_seqs(str(pl))
+    assert names == ["", ""] and list(off) == [0, 3, 6]
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">x\nAC-D\n")
+    with pytest.raises(swg.SwgError) as e:
+        swg.read_seqs(str(bad))
+    assert e.value.code == swg.SWG_ERR_RESIDUE
+    with pytest.raises(swg.SwgError):
+        swg.read_seqs(str(tmp_path / "nope.fa"))
+
+
+def test_pack_orders_bins_and_validates(swg):
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1, 300, size=1000)
+    off = np.zeros(1001, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    flat = rng.integers(1, 26, size=int(off[-1])).astype(np.int8)
+    db = swg.Database(flat, off)
+    assert db.count == 1000 and db.total_count == 1000 and db.residues == int(off[-1])
+    order = db.order()
+    assert sorted(order) == list(range(1000))
+    sl = lens[order]
+    assert (np.diff(sl) <= 0).all()                      # longest first
+    for L in np.unique(sl):                              # stable among equal lengths
+        o = order[sl == L]
+        assert (np.diff(o) > 0).all()
+    # padded footprint: 128 slots x ceil(maxlen/4) dwords per bin
+    nb = (1000 + 127) // 128
+    expect = sum(((int(sl[b * 128]) + 3) // 4) * 128 * 4 for b in range(nb))
+    assert db.packed_bytes == expect + nb * 12
+    # shards partition the bins round-robin
+    seen = []
+    for r in range(3):
+        s = swg.Database(flat, off, r, 3)
+        o = s.order()
+        want = np.concatenate([order[b * 128:(b + 1) * 128] for b in range(r, nb, 3)])
+        assert np.array_equal(o, want)
+        seen += list(o)
+    assert sorted(seen) == list(range(1000))
+    # residue 0 / out of range / bad shard -> error codes, never a crash
+    bad = flat.copy()
+    bad[5] = 0
+    with pytest.raises(swg.SwgError) as e:
+        swg.Database(bad, off)
+    assert e.value.code == swg.SWG_ERR_RESIDUE
+    with pytest.raises(swg.SwgError):
+        swg.Database(flat, off, 3, 3)
+    empty = swg.Database(np.zeros(0, np.int8), np.zeros(1, np.uint64))
+    assert empty.count == 0
+
+
+def test_synthetic_data_is_deterministic_and_shaped(swg):
+    f1, o1 = swg.synth_db(0x5EED0002, 2000)
+    f2, o2 = swg.synth_db(0x5EED0002, 2000)
+    assert np.array_equal(f1, f2) and np.array_equal(o1, o2)
+    f3, _ = swg.synth_db(0x5EED0003, 2000)
+    assert not np.array_equal(f1[:1000], f3[:1000])
+    lens = np.diff(o1.astype(np.int64))
+    assert (np.diff(lens) <= 0).all() and lens.min() >= 20 and lens.max() <= 5000
+    assert 250 < np.median(lens) < 340 and 330 < lens.mean() < 420
+    letters = set(chr(swg.lib.swg_index_letter(int(v))) for v in np.unique(f1))
+    assert letters == set("ARNDCQEGHILKMFPSTWYV")
+    freq_l = (f1 == swg.lib.swg_letter_index(ord("L"))).mean()
+    assert 0.085 < freq_l < 0.108
+    q = swg.synth_query(0x5EED0002, 367)
+    assert q.size == 367 and np.array_equal(q, swg.synth_query(0x5EED0002, 367))
+    fs, os_, planted = swg.synth_db(7, 500, query=q, fraction=0.1, subst=0.05)
+    lens = np.diff(os_.astype(np.int64))
+    assert 20 < planted < 90 and (lens == 367).sum() >= planted
+    k = int(np.nonzero(lens == 367)[0][0])
+    same = (fs[int(os_[k]):int(os_[k + 1])] == q).mean()
+    assert same > 0.9
+
+
+def test_hit_keys_and_merge(swg, orc):
+    assert swg.key_hit(swg.hit_key(1234, 77)) == (1234, 77)
+    assert swg.hit_key(10, 5) > swg.hit_key(10, 6) > swg.hit_key(9, 0)   # score, then lower index
+    rng = np.random.default_rng(1)
+    scores = rng.integers(0, 50, size=5000).astype(np.int32)
+    keys = np.array([swg.hit_key(int(s), i) for i, s in enumerate(scores)], dtype=np.uint64)
+    for k in (1, 10, 100, 6000):
+        assert swg.topk_merge_keys(keys, k) == orc.topk(scores, k)
+    # merging per-shard lists gives the global list
+    parts = [swg.topk_merge_keys(keys[r::4], 100) for r in range(4)]
+    shard_keys = np.array([swg.hit_key(s, i) for p in parts for (s, i) in p] + [0, 0], dtype=np.uint64)
+    assert swg.topk_merge_keys(shard_keys, 100) == orc.topk(scores, 100)
