@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--max-waves", type=int, default=0)
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--uniform-len", type=int, default=0,
+                    help="diagnostic: every sequence gets this length (no length tail)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     args = ap.parse_args()
 
@@ -80,6 +82,8 @@ def main():
     shard_seed = seed + 0x10000 * rank          # every rank: an independent shard of the same shape
     if cfg.get("similar"):
         flat, off, _ = swg.synth_db(shard_seed, n, query=q, fraction=cfg["similar"], subst=0.05)
+    elif args.uniform_len:
+        flat, off = swg.synth_db(shard_seed, n, min_len=args.uniform_len, max_len=args.uniform_len)
     else:
         flat, off = swg.synth_db(shard_seed, n)
 
