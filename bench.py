@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--max-waves", type=int, default=0)
     ap.add_argument("--workgroups", type=int, default=0)
+    ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 systolic, 2 diagonal")
+    ap.add_argument("--group", type=int, default=0, help="diagonal engine: lanes per sequence pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
@@ -93,6 +95,8 @@ def main():
     ctx.set_option("cols_per_wave", args.cols)
     ctx.set_option("max_waves", args.max_waves)
     ctx.set_option("workgroups", args.workgroups)
+    ctx.set_option("engine", args.engine)
+    ctx.set_option("group_lanes", args.group)
     db = swg.Database(flat, off).upload(ctx)
     residues = int(db.residues)
 
@@ -169,12 +173,15 @@ def main():
                 "lq": lq, "n_seqs_per_gpu": n, "residues_per_gpu": residues, "matrix": cfg["matrix"],
                 "cols_per_wave": last["cols_per_wave"], "waves": last["waves"], "passes": last["passes"],
                 "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
+                "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
+                "streams": last["streams"],
                 "cells_padded_over_real": round(last["cells_padded"] / max(1, last["cells"]), 4),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": "swg_fill_kernel<CellsI%d>" % last["path_bits"], "kernel_ms": round(k_ms, 4),
+                "kernel": ("swg_diag_kernel<%d>" % last["cols_per_wave"]) if last["engine"] == 2
+                else "swg_fill_kernel<CellsI%d>" % last["path_bits"], "kernel_ms": round(k_ms, 4),
                 "bytes_alg_per_launch": bytes_alg,
                 "binding_roof": {"bound": "valu_int", "kernel_gcups": round(kernel_gcups, 2),
                                  "ops_per_cell": ops_per_cell,

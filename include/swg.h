@@ -75,7 +75,9 @@ typedef struct swg_stats {
     int32_t waves;          /* W: wavefronts of one systolic workgroup */
     int32_t passes;         /* query passes (ceil(lq / (W*K))) */
     int32_t workgroups;     /* grid size of the fill */
-    int32_t reserved[3];
+    int32_t engine;         /* 1 systolic (waves chained over the query), 2 diagonal (lane groups) */
+    int32_t group_lanes;    /* diagonal engine: lanes sharing one pair of sequences (16/32/64) */
+    int32_t streams;        /* diagonal engine: lane groups working in parallel */
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */
@@ -89,7 +91,10 @@ const char *swg_global_error(void); /* errors of calls that have no context */
 int swg_abi_version(void);
 
 /* Tuning / test switches.  Keys: "force_bits" (0 auto | 16 | 32),
- * "cols_per_wave" (0 auto | 8..64, multiple of 4), "max_waves" (0 auto | 1..16),
+ * "engine" (0 auto | 1 systolic | 2 diagonal; int16 path only),
+ * "cols_per_wave" (0 auto | query columns a lane keeps in registers, multiple of 4),
+ * "max_waves" (0 auto | systolic: waves chained over the query, 1..16; diagonal:
+ * waves per workgroup, multiple of 4), "group_lanes" (0 auto | 16 | 32 | 64),
  * "workgroups" (0 auto). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 

@@ -63,7 +63,8 @@ class Stats(C.Structure):
         ("n_rescored", C.c_uint64), ("fill_ms", C.c_double), ("rescore_ms", C.c_double),
         ("topk_ms", C.c_double), ("total_ms", C.c_double), ("path_bits", C.c_int32),
         ("cols_per_wave", C.c_int32), ("waves", C.c_int32), ("passes", C.c_int32),
-        ("workgroups", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("workgroups", C.c_int32), ("engine", C.c_int32), ("group_lanes", C.c_int32),
+        ("streams", C.c_int32),
     ]
 
     def as_dict(self):

@@ -30,7 +30,7 @@ ARCH = "gfx950"
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 
 HIP_SOURCES = ["swg_kernels.hip", "swg_api.cpp"]
-CXX_SOURCES = ["swg_pack.cpp"]  # host-only C++, OpenMP via g++
+CXX_SOURCES = ["swg_pack.cpp", "swg_diag_host.cpp"]  # host-only C++, OpenMP via g++
 C_SOURCES = ["swg_scoring.c", "swg_seqio.c", "swg_synth.c"]
 CLI_SOURCES = ["sw_cmdline.c"]
 

@@ -123,6 +123,13 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
     } else if (!strcmp(key, "max_waves")) {
         if (value < 0 || value > 16) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "max_waves must be 0..16");
         ctx->opt_max_waves = value;
+    } else if (!strcmp(key, "engine")) {
+        if (value < 0 || value > 2) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "engine must be 0 (auto), 1 (systolic) or 2 (diagonal)");
+        ctx->opt_engine = value;
+    } else if (!strcmp(key, "group_lanes")) {
+        if (value != 0 && value != 16 && value != 32 && value != 64)
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "group_lanes must be 0, 16, 32 or 64");
+        ctx->opt_group = value;
     } else if (!strcmp(key, "workgroups")) {
         if (value < 0) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "workgroups must be >= 0");
         ctx->opt_workgroups = value;
@@ -188,6 +195,12 @@ void swg_db_release_device(swg_db *db)
     (void)hipFree(db->d_list);
     (void)hipFree(db->d_counters);
     (void)hipFree(db->d_keys);
+    (void)hipFree(db->diag.d_tok);
+    (void)hipFree(db->diag.d_stream_off);
+    (void)hipFree(db->diag.d_stream_pairs);
+    (void)hipFree(db->diag.d_stream_pair_off);
+    (void)hipFree(db->diag.d_scratch);
+    db->diag = SwgDiagLayout();
     db->d_packed = nullptr;
     db->d_bin_off = nullptr;
     db->d_bin_nblk = nullptr;
@@ -276,12 +289,10 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
     return SWG_OK;
 }
 
-static int ensure_profile(swg_ctx *ctx, const Plan &pl)
+static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom)
 {
-    const int which = pl.bits == 16 ? 0 : 1;
-    const uint32_t ncols = (uint32_t)(pl.npass * pl.W * pl.K);
-    const size_t bytes = (size_t)ncols * 32 * pl.info.elem_size;
-    const uint64_t tag = (ctx->epoch << 32) ^ ((uint64_t)pl.K << 20) ^ ((uint64_t)pl.W << 12) ^ (uint64_t)pl.npass;
+    const size_t bytes = (size_t)ncols * 32 * elem_size;
+    const uint64_t tag = (ctx->epoch << 32) ^ geom;
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
     if (bytes > ctx->d_profile_cap[which]) {
         (void)hipFree(ctx->d_profile[which]);
@@ -291,8 +302,58 @@ static int ensure_profile(swg_ctx *ctx, const Plan &pl)
         ctx->d_profile_cap[which] = bytes;
     }
     HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols,
-                                          pl.info.elem_size, ctx->d_profile[which], ctx->stream));
+                                          elem_size, ctx->d_profile[which], ctx->stream));
     ctx->profile_tag[which] = tag;
+    return SWG_OK;
+}
+
+static int ensure_profile(swg_ctx *ctx, const Plan &pl)
+{
+    return ensure_profile_cols(ctx, pl.bits == 16 ? 0 : 1, (uint32_t)(pl.npass * pl.W * pl.K), pl.info.elem_size,
+                               ((uint64_t)pl.K << 20) ^ ((uint64_t)pl.W << 12) ^ (uint64_t)pl.npass);
+}
+
+// Stream layout of the diagonal engine for this database at this stream count,
+// built on the host and kept resident until the geometry changes.
+static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, const SwgDiagPlan &pl)
+{
+    SwgDiagLayout &L = db->diag;
+    const uint32_t spw = (uint32_t)(pl.W * (64 / pl.G));
+    if (L.n_streams != pl.n_streams || L.streams_per_wg != spw || !L.d_tok) {
+        (void)hipFree(L.d_tok);
+        (void)hipFree(L.d_stream_off);
+        (void)hipFree(L.d_stream_pairs);
+        (void)hipFree(L.d_stream_pair_off);
+        (void)hipFree(L.d_scratch);
+        L = SwgDiagLayout();
+        try {
+            swg_build_diag_layout(db, pl.n_streams, spw, &L);
+            L.streams_per_wg = spw;
+        } catch (const std::bad_alloc &) {
+            L = SwgDiagLayout();
+            return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "diagonal layout: out of host memory");
+        }
+        const size_t S = L.n_streams;
+        HIP_TRY(ctx, hipMalloc(&L.d_tok, std::max<size_t>(8, L.tok.size() * 4)));
+        HIP_TRY(ctx, hipMalloc(&L.d_stream_off, (S + 1) * 8));
+        HIP_TRY(ctx, hipMalloc(&L.d_stream_pairs, std::max<size_t>(4, L.stream_pairs.size() * 4)));
+        HIP_TRY(ctx, hipMalloc(&L.d_stream_pair_off, (S + 1) * 4));
+        HIP_TRY(ctx, hipMemcpyAsync(L.d_tok, L.tok.data(), L.tok.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(L.d_stream_off, L.stream_off.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(L.d_stream_pairs, L.stream_pairs.data(), L.stream_pairs.size() * 4,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(L.d_stream_pair_off, L.stream_pair_off.data(), (S + 1) * 4,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t>().swap(L.tok); // the device copy is the one that is used
+    }
+    if (pl.npass > 1 && L.d_scratch_rows < L.total_blocks * 4) {
+        (void)hipFree(L.d_scratch);
+        L.d_scratch = nullptr;
+        L.d_scratch_rows = 0;
+        HIP_TRY(ctx, hipMalloc(&L.d_scratch, std::max<size_t>(8, L.total_blocks * 4 * sizeof(uint2))));
+        L.d_scratch_rows = L.total_blocks * 4;
+    }
     return SWG_OK;
 }
 
@@ -368,7 +429,24 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
 
     Plan main_pl, re_pl;
     int rc = make_plan(ctx, bits, bits == 16 ? n_bins : n_bins * 2, &main_pl);
-    if (rc != SWG_OK) return rc;
+    if (rc != SWG_OK && !(bits == 16 && ctx->opt_engine != 1)) return rc;
+    // int16: the diagonal engine unless the systolic one is asked for
+    SwgDiagPlan dpl;
+    bool use_diag = false;
+    if (bits == 16 && ctx->opt_engine != 1) {
+        uint64_t longest_rows = 0;
+        const uint64_t pair_rows = swg_db_pair_rows(db, &longest_rows);
+        use_diag = swg_plan_diag(lq, (db->n_local + 1) / 2, pair_rows, longest_rows, ctx->n_cu, ctx->opt_cols,
+                                 ctx->opt_group, ctx->opt_max_waves, &dpl);
+        if (!use_diag && ctx->opt_engine == 2)
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
+        if (use_diag && ctx->opt_workgroups > 0) {
+            const uint64_t per_wg = (uint64_t)dpl.W * (64 / dpl.G);
+            dpl.workgroups = (int)std::min<long>(ctx->opt_workgroups, dpl.workgroups);
+            dpl.n_streams = (uint32_t)((uint64_t)dpl.workgroups * per_wg);
+        }
+        if (!use_diag && rc != SWG_OK) return rc;
+    }
     // can an int16 score saturate at all?  score <= min(lq, longest) * max(S)
     int smax = 0;
     for (int a = 0; a < 32; ++a)
@@ -382,12 +460,19 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         ctx->opt_cols = keep_cols;
         if (rc != SWG_OK) return rc;
     }
-    rc = ensure_profile(ctx, main_pl);
+    if (use_diag) {
+        rc = ensure_diag_layout(ctx, const_cast<swg_db *>(db), dpl);
+        if (rc != SWG_OK) return rc;
+        rc = ensure_profile_cols(ctx, 0, (uint32_t)(dpl.npass * dpl.G * dpl.K), 2,
+                                 (1ull << 31) ^ ((uint64_t)dpl.K << 20) ^ ((uint64_t)dpl.G << 12) ^ (uint64_t)dpl.npass);
+    } else {
+        rc = ensure_profile(ctx, main_pl);
+    }
     if (rc != SWG_OK) return rc;
     if (may_saturate && (rc = ensure_profile(ctx, re_pl)) != SWG_OK) return rc;
     {
         size_t need = 0;
-        if (main_pl.npass > 1)
+        if (!use_diag && main_pl.npass > 1)
             need = std::max(need, (size_t)main_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb);
         if (may_saturate && re_pl.npass > 1)
             need = std::max(need, (size_t)re_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * re_pl.info.nb);
@@ -409,7 +494,30 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     p.scratch = ctx->d_scratch;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    {
+    if (use_diag) {
+        SwgDiagParams d;
+        memset(&d, 0, sizeof d);
+        d.tok = db->diag.d_tok;
+        d.stream_off = db->diag.d_stream_off;
+        d.stream_pairs = db->diag.d_stream_pairs;
+        d.stream_pair_off = db->diag.d_stream_pair_off;
+        d.n_streams = db->diag.n_streams;
+        d.profile = ctx->d_profile[0];
+        d.scores = db->d_scores;
+        d.scratch = db->diag.d_scratch;
+        d.npass = (uint32_t)dpl.npass;
+        d.G = (uint32_t)dpl.G;
+        const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
+        d.go = g | (g << 16);
+        d.ge = e | (e << 16);
+        // streams that hold little more than one very long pair are the critical path:
+        // their wavefronts get issue priority over the ones they share a SIMD with
+        const double mean_blocks = (double)db->diag.total_blocks / std::max<uint32_t>(1, db->diag.n_streams);
+        d.prio_blocks = (double)db->diag.max_stream_blocks > 1.1 * mean_blocks
+                            ? (uint32_t)(0.75 * (double)db->diag.max_stream_blocks)
+                            : 0xFFFFFFFFu;
+        HIP_TRY(ctx, swg_launch_diag(dpl.variant, dpl.npass > 1, dpl.W, dpl.workgroups, dpl.lds_bytes, d, s));
+    } else {
         p.profile = ctx->d_profile[bits == 16 ? 0 : 1];
         p.queue = db->d_counters + 0;
         p.list = nullptr;
@@ -464,11 +572,23 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     st.total_ms = ms;
     st.n_rescored = h_counters[1];
     st.path_bits = bits;
-    st.cols_per_wave = main_pl.K;
-    st.waves = main_pl.W;
-    st.passes = main_pl.npass;
-    st.workgroups = main_pl.workgroups;
-    st.cells_padded = (uint64_t)main_pl.npass * main_pl.W * main_pl.K * db->rows_padded;
+    if (use_diag) {
+        st.engine = 2;
+        st.cols_per_wave = dpl.K;
+        st.group_lanes = dpl.G;
+        st.waves = dpl.W;
+        st.passes = dpl.npass;
+        st.workgroups = dpl.workgroups;
+        st.streams = (int32_t)db->diag.n_streams;
+        st.cells_padded = 2ull * dpl.npass * dpl.G * dpl.K * db->diag.total_blocks * 4ull;
+    } else {
+        st.engine = 1;
+        st.cols_per_wave = main_pl.K;
+        st.waves = main_pl.W;
+        st.passes = main_pl.npass;
+        st.workgroups = main_pl.workgroups;
+        st.cells_padded = (uint64_t)main_pl.npass * main_pl.W * main_pl.K * db->rows_padded;
+    }
 
     const auto t0 = std::chrono::steady_clock::now();
     if (scores_out) {

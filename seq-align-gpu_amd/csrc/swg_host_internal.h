@@ -7,6 +7,27 @@
 #include <string>
 #include <vector>
 
+// Stream layout of the diagonal engine: pairs of adjacent sorted ranks, dealt to
+// n_streams lane groups longest first; tokens are stored stream-major.
+struct SwgDiagLayout {
+    uint32_t n_streams = 0;
+    uint32_t streams_per_wg = 0;
+    uint64_t total_blocks = 0;      // 4-row token blocks over all streams
+    uint64_t max_stream_blocks = 0;
+    uint64_t pair_rows_total = 0;   // sum over pairs of (2 + longer length), unpadded
+    std::vector<uint64_t> stream_off;      // [n_streams+1]
+    std::vector<uint32_t> stream_pairs;    // pair ids, stream-major
+    std::vector<uint32_t> stream_pair_off; // [n_streams+1]
+    std::vector<uint32_t> tok;             // 2 dwords per block
+    // device image
+    uint2 *d_tok = nullptr;
+    uint64_t *d_stream_off = nullptr;
+    uint32_t *d_stream_pairs = nullptr;
+    uint32_t *d_stream_pair_off = nullptr;
+    uint2 *d_scratch = nullptr;
+    uint64_t d_scratch_rows = 0;
+};
+
 struct swg_db {
     // host image
     size_t n_total = 0;             // sequences given to swg_db_pack
@@ -19,7 +40,10 @@ struct swg_db {
     std::vector<uint32_t> bin_nblk; // [n_bins]
     std::vector<uint32_t> order;    // [n_bins*128] original index of each slot, ~0u = empty
     std::vector<uint32_t> lens;     // [n_bins*128]
-    std::vector<uint32_t> packed;   // residue dwords
+    std::vector<uint32_t> packed;   // residue dwords (bins, systolic engine)
+    std::vector<uint8_t> codes;     // residue bytes (index<<3) by sorted rank, back to back
+    std::vector<uint64_t> code_off; // [n_bins*128+1]
+    SwgDiagLayout diag;             // stream layout of the diagonal engine (built on demand)
     // device image (valid after swg_db_upload)
     int device = -1;
     uint32_t *d_packed = nullptr;
@@ -44,7 +68,7 @@ struct swg_ctx {
     // query
     std::vector<int8_t> query;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0;
     // device state
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;
@@ -62,3 +86,16 @@ int swg_set_global_error(int code, const char *fmt, ...) __attribute__((format(p
 int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
     __attribute__((format(printf, 3, 4)));
 void swg_db_release_device(swg_db *db);
+
+// swg_diag_host.cpp (host only)
+struct SwgDiagPlan {
+    int variant, K, G, npass, W, workgroups;
+    uint32_t n_streams;
+    size_t lds_bytes;
+    double est_ms;
+};
+// geometry for one query length on one device; returns false if the diagonal engine cannot run it
+bool swg_plan_diag(size_t lq, uint64_t n_pairs, uint64_t pair_rows_total, uint64_t longest_rows, int n_cu,
+                   long opt_cols, long opt_group, long opt_waves, SwgDiagPlan *out);
+void swg_build_diag_layout(const swg_db *db, uint32_t n_streams, uint32_t streams_per_wg, SwgDiagLayout *out);
+uint64_t swg_db_pair_rows(const swg_db *db, uint64_t *longest_rows);

@@ -6,14 +6,16 @@
 
 // Database layout in HBM (built by swg_db_pack, swg_pack.cpp):
 //   sequences sorted by length (descending), 128 consecutive ones form a BIN;
-//   a bin of nblk row-blocks is nblk*128 dwords:  dword[blk*128 + slot] holds
-//   rows 4*blk..4*blk+3 of sequence `slot`, one byte per row, byte = index<<3
+//   a bin of nblk row-blocks is nblk*128 dwords:  dword[blk*128 + SWG_BIN_COLUMN(rank)]
+//   holds rows 4*blk..4*blk+3 of the bin's rank-th sequence, one byte per row, byte = index<<3
 //   (the LDS byte offset of that residue's profile row inside a 256-byte chunk);
 //   rows past a sequence's end are 0 = the padding residue.
 // A wavefront therefore reads 64 consecutive dwords (256 B) per row-block per
 // half-bin: fully coalesced, each residue byte fetched from HBM exactly once.
 #define SWG_BIN 128        // sequences per bin (64 lanes x 2 packed int16 halves)
 #define SWG_ROWS_PER_BLK 4 // DB rows per row-block = residues per dword
+// dword column of a bin's sorted rank s: ranks 2l and 2l+1 share lane l (low/high int16 half)
+#define SWG_BIN_COLUMN(s) ((((s)&1u) * 64u) + ((s) >> 1))
 
 struct SwgFillParams {
     const uint32_t *residues;   // packed bins
@@ -33,6 +35,21 @@ struct SwgFillParams {
     uint64_t scratch_wg_dwords; // dwords of scratch owned by one workgroup
 };
 
+// Diagonal engine (swg_diag_kernel): streams of sequence pairs, one per lane group.
+struct SwgDiagParams {
+    const uint2 *tok;                // stream-major token blocks (4 rows = 8 bytes each)
+    const uint64_t *stream_off;      // [n_streams+1] block offset of each stream
+    const uint32_t *stream_pairs;    // pair ids in stream order
+    const uint32_t *stream_pair_off; // [n_streams+1]
+    uint32_t n_streams;
+    const uint8_t *profile;          // [npass][G*K/4][32][4] int16
+    int32_t *scores;                 // by sorted rank: pair p -> 2p, 2p+1
+    uint2 *scratch;                  // multi-pass spill, one (M,B) per stream row
+    uint32_t npass, G;
+    uint32_t go, ge;                 // |gap_open+gap_extend|, |gap_extend| in both halves
+    uint32_t prio_blocks;            // wavefronts whose longest stream has >= this many blocks run at raised priority
+};
+
 struct SwgKernelInfo {
     int bits;      // 16 or 32
     int K;         // query columns per wavefront
@@ -48,6 +65,11 @@ int swg_num_variants(int bits);
 SwgKernelInfo swg_variant_info(int bits, int variant);
 hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups,
                            const SwgFillParams &p, hipStream_t stream);
+
+int swg_num_diag_variants();
+SwgKernelInfo swg_diag_variant_info(int variant); // K, max_waves (wave budget of one CU)
+hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, size_t lds_bytes,
+                           const SwgDiagParams &p, hipStream_t stream);
 
 // profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
 // col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.

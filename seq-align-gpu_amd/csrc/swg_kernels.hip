@@ -299,8 +299,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
                         my_nblk = nblk_real;
                         rptr[0] = p.residues + p.bin_off[item] + lane;
                         rptr[1] = rptr[0] + 64;
-                        sid[0] = item * SWG_BIN + lane;
-                        sid[1] = sid[0] + 64;
+                        sid[0] = item * SWG_BIN + 2u * lane; // lane l: sorted ranks 2l, 2l+1 of the bin
+                        sid[1] = sid[0] + 1u;
                     } else {
                         const uint32_t gi = item * 64u + lane;
                         uint32_t s;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
                         }
                         const uint32_t b = s / SWG_BIN;
                         my_nblk = valid ? (int)p.bin_nblk[b] : 0;
-                        rptr[0] = p.residues + (valid ? p.bin_off[b] : 0) + (s % SWG_BIN);
+                        rptr[0] = p.residues + (valid ? p.bin_off[b] : 0) + SWG_BIN_COLUMN(s % SWG_BIN);
                         sid[0] = valid ? s : 0xFFFFFFFFu;
                         nblk_real = __builtin_amdgcn_readfirstlane(
                             (int)wave_max_u32((uint32_t)my_nblk));
@@ -398,6 +398,207 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 }
 
 // ---------------------------------------------------------------------------
+// The diagonal fill: G lanes share one pair of sequences
+// ---------------------------------------------------------------------------
+// Same packed recurrence, finer decomposition.  A group of G lanes (16, 32 or 64)
+// owns ONE pair of database sequences; lane g of the group holds K query columns
+// [g*K, (g+1)*K) and works on database row (t - g) at step t, so the group sweeps
+// the DP matrix as an anti-diagonal wavefront.  What crosses a lane boundary per
+// step -- the strip's right edge (M, B), the residue token and the running
+// maximum -- moves with DPP lane shifts (row_shr:1 inside a 16-lane row,
+// wave_shr:1 across the wavefront); nothing goes through LDS or memory.
+//
+// Why it exists next to the systolic kernel: there a lane walks K=32 columns of
+// 128 lock-stepped sequences, so a bin of long sequences is a serial chain of
+// rows*K*11 instructions on one CU while the rest of the chip drains; here the
+// chain is rows*(K/G-th of the query), the unit of scheduling is a pair of
+// sequences instead of 128, and sequences stream through a lane group back to
+// back (two all-padding "reset" rows between pairs clear the carried state), so
+// there is no pipeline fill per sequence and no padding to a bin's longest
+// member.  Streams of pairs are balanced on the host (longest first).
+//
+// Token per database row: byte 0 = X residue (index<<3) | flags, byte 1 = Y
+// residue (index<<3); flags bit0 = reset row, bit1 = last row of the pair.
+#define SWG_TOK_RESET 1u
+#define SWG_TOK_LAST 2u
+#define DPP_ROW_SHR1 0x111
+#define DPP_WAVE_SHR1 0x138
+
+template <int K> struct CellsDiag {
+    static constexpr int CHUNK = 256;
+    uint32_t M[K], G[K], A[K];
+    uint32_t best, mdl;
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) M[k] = G[k] = A[k] = 0u;
+        best = 0u;
+        mdl = 0u;
+    }
+
+    // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows)
+    DEVINL uint2 row(const uint8_t *prof, uint32_t offx, uint32_t offy, uint32_t em, uint32_t eb,
+                     uint32_t go, uint32_t ge)
+    {
+        uint32_t md = mdl;
+        uint32_t gl = pk_sub_u16_sat(em, go);
+        uint32_t bl = eb;
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) {
+            const uint2 wx = *reinterpret_cast<const uint2 *>(prof + offx + c * CHUNK);
+            const uint2 wy = *reinterpret_cast<const uint2 *>(prof + offy + c * CHUNK);
+            uint32_t s[4];
+            s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
+            s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
+            s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
+            s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * c + u;
+                const uint32_t t = pk_add_i16_sat(md, s[u]);
+                md = M[k];
+                const uint32_t a = pk_max_i16(G[k], pk_sub_u16_sat(A[k], ge));
+                const uint32_t b = pk_max_i16(gl, pk_sub_u16_sat(bl, ge));
+                const uint32_t m = pk_max_i16(pk_max_i16(t, a), b);
+                M[k] = m;
+                A[k] = a;
+                gl = G[k] = pk_sub_u16_sat(m, go);
+                bl = b;
+                best = pk_max_i16(best, m);
+            }
+        }
+        mdl = em;
+        return make_uint2(M[K - 1], bl);
+    }
+};
+
+template <int CTRL> DEVINL uint32_t dpp_keep(uint32_t keep, uint32_t src)
+{
+    // lanes without a source lane keep `keep`
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)keep, (int)src, CTRL, 0xf, 0xf, false);
+}
+
+template <int K, int MAXW, bool MULTIPASS>
+__global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile of this pass
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const int G = (int)p.G;
+    const int g = lane & (G - 1);
+    const bool leader = g == 0, tail = g == G - 1;
+    const uint32_t stream = (uint32_t)((blockIdx.x * W + w) * (64 / G) + lane / G);
+    uint64_t boff = 0;
+    uint32_t nblk = 0, pair0 = 0;
+    if (stream < p.n_streams) {
+        boff = p.stream_off[stream];
+        nblk = (uint32_t)(p.stream_off[stream + 1] - boff);
+        pair0 = p.stream_pair_off[stream];
+    }
+    const uint32_t wave_nblk = __builtin_amdgcn_readfirstlane(wave_max_u32(nblk));
+    const uint32_t nsteps = wave_nblk * 4u + (uint32_t)G; // >= rows + G - 1, multiple of 4
+    if (wave_nblk >= p.prio_blocks) __builtin_amdgcn_s_setprio(3);
+    const uint32_t rows = nblk * 4u;
+    const uint2 *tp = p.tok + boff;
+    uint2 *sp = p.scratch + boff * 4u;
+    const uint32_t base = (uint32_t)g * (K / 4) * 256u;
+    const uint32_t slice = (uint32_t)G * K * 64u;
+    const int npass = MULTIPASS ? (int)p.npass : 1;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        if (MULTIPASS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // spills of the previous pass
+            __syncthreads();
+        }
+        {
+            const uint8_t *src = p.profile + (size_t)pass * slice;
+            for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
+                *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(src + o);
+        }
+        __syncthreads();
+
+        CellsDiag<K> cells;
+        cells.reset();
+        uint32_t tok = 0u, m_out = 0u, b_out = 0u, c_out = 0u, done = 0u;
+        uint2 cur = (leader && nblk > 0u) ? tp[0] : make_uint2(0u, 0u);
+        uint2 nxt = (leader && nblk > 1u) ? tp[1] : make_uint2(0u, 0u);
+        uint2 spc[4], spn[4];
+        if (MULTIPASS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                spc[r] = (leader && pass > 0 && (uint32_t)r < rows) ? load_edge_l2(sp + r) : make_uint2(0u, 0u);
+                spn[r] = (leader && pass > 0 && 4u + r < rows) ? load_edge_l2(sp + 4 + r) : make_uint2(0u, 0u);
+            }
+        }
+
+        for (uint32_t s4 = 0; s4 < nsteps; s4 += 4u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t word = (r & 2) ? cur.y : cur.x;
+                const uint32_t fresh = (r & 1) ? (word >> 16) : (word & 0xFFFFu);
+                const uint32_t lm = MULTIPASS ? spc[r].x : 0u, lb = MULTIPASS ? spc[r].y : 0u;
+                uint32_t em, eb, cin;
+                if (G == 16) {
+                    tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
+                    em = dpp_keep<DPP_ROW_SHR1>(lm, m_out);
+                    eb = dpp_keep<DPP_ROW_SHR1>(lb, b_out);
+                    cin = dpp_keep<DPP_ROW_SHR1>(0u, c_out);
+                } else {
+                    const uint32_t t0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
+                    const uint32_t t1 = dpp_keep<DPP_WAVE_SHR1>(lm, m_out);
+                    const uint32_t t2 = dpp_keep<DPP_WAVE_SHR1>(lb, b_out);
+                    const uint32_t t3 = dpp_keep<DPP_WAVE_SHR1>(0u, c_out);
+                    if (G == 32) { // lane 32 starts a group too
+                        tok = leader ? fresh : t0;
+                        em = leader ? lm : t1;
+                        eb = leader ? lb : t2;
+                        cin = leader ? 0u : t3;
+                    } else {
+                        tok = t0;
+                        em = t1;
+                        eb = t2;
+                        cin = t3;
+                    }
+                }
+                // reset rows: gap magnitudes of all ones wipe A/G/B, two such rows wipe M
+                const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
+                cells.best &= ~fm;
+                const uint2 e = cells.row(smem, base + (tok & 0xF8u), base + ((tok >> 8) & 0xF8u), em, eb,
+                                          p.go | fm, p.ge | fm);
+                m_out = e.x;
+                b_out = e.y;
+                c_out = pk_max_i16(cin, cells.best);
+                if (tail) {
+                    if (tok & SWG_TOK_LAST) {
+                        const uint32_t pr = p.stream_pairs[pair0 + done];
+                        atomicMax(p.scores + 2u * pr, (int)(c_out & 0xFFFFu));
+                        atomicMax(p.scores + 2u * pr + 1u, (int)(c_out >> 16));
+                        ++done;
+                    }
+                    if (MULTIPASS) {
+                        const uint32_t row = s4 + (uint32_t)r - (uint32_t)(G - 1);
+                        if (pass + 1 < npass && row < rows) sp[row] = e; // row wraps negative -> huge
+                    }
+                }
+            }
+            const uint32_t bi = s4 / 4u + 2u;
+            cur = nxt;
+            nxt = (leader && bi < nblk) ? tp[bi] : make_uint2(0u, 0u);
+            if (MULTIPASS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    spc[r] = spn[r];
+                    const uint32_t row = (bi)*4u + (uint32_t)r;
+                    spn[r] = (leader && pass > 0 && row < rows) ? load_edge_l2(sp + row) : make_uint2(0u, 0u);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------
 __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
@@ -466,6 +667,64 @@ const Variant *variants32(int *n)
 }
 const Variant *variants(int bits, int *n) { return bits == 16 ? variants16(n) : variants32(n); }
 } // namespace
+
+namespace {
+struct DiagVariant {
+    SwgKernelInfo info;
+    void (*kernel[2])(const SwgDiagParams); // [0] single pass, [1] multi-pass
+};
+template <int K, int MAXW> DiagVariant make_diag()
+{
+    DiagVariant v;
+    v.info.bits = 16;
+    v.info.K = K;
+    v.info.max_waves = MAXW;
+    v.info.nb = 2;
+    v.info.elem_size = 2;
+    v.info.lds_per_wave = 0;
+    v.info.lds_fixed = 0;
+    v.kernel[0] = swg_diag_kernel<K, MAXW, false>;
+    v.kernel[1] = swg_diag_kernel<K, MAXW, true>;
+    return v;
+}
+const DiagVariant *diag_variants(int *n)
+{
+    static const DiagVariant v[] = {
+        make_diag<24, 16>(), make_diag<12, 16>(), make_diag<8, 16>(), make_diag<16, 16>(), make_diag<32, 12>(),
+    };
+    *n = (int)(sizeof(v) / sizeof(v[0]));
+    return v;
+}
+} // namespace
+
+int swg_num_diag_variants()
+{
+    int n;
+    diag_variants(&n);
+    return n;
+}
+
+SwgKernelInfo swg_diag_variant_info(int variant)
+{
+    int n;
+    return diag_variants(&n)[variant].info;
+}
+
+hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, size_t lds_bytes,
+                           const SwgDiagParams &p, hipStream_t stream)
+{
+    int n;
+    const DiagVariant *v = diag_variants(&n);
+    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
+        (p.G != 16 && p.G != 32 && p.G != 64))
+        return hipErrorInvalidValue;
+    auto k = v[variant].kernel[multipass ? 1 : 0];
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds_bytes, stream, p);
+    return hipGetLastError();
+}
 
 int swg_num_variants(int bits)
 {

@@ -107,6 +107,15 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
                                     (unsigned long long)dwords);
     }
 
+    try {
+        db->code_off.assign(nb * SWG_BIN + 1, 0);
+        for (size_t i = 0; i < nb * SWG_BIN; ++i) db->code_off[i + 1] = db->code_off[i] + db->lens[i];
+        db->codes.assign(residues, 0);
+    } catch (const std::bad_alloc &) {
+        delete db;
+        return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
+    }
+
     uint32_t *pk = db->packed.data();
 #pragma omp parallel for schedule(dynamic, 4)
     for (long long lb = 0; lb < (long long)nb; ++lb) {
@@ -116,11 +125,13 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
             if (oi == 0xFFFFFFFFu) continue;
             const int8_t *src = flat + offsets[oi];
             const uint32_t len = db->lens[lb * SWG_BIN + s];
+            uint8_t *cd = db->codes.data() + db->code_off[lb * SWG_BIN + s];
+            for (uint32_t j = 0; j < len; ++j) cd[j] = (uint8_t)((uint8_t)src[j] << 3);
             for (uint32_t j = 0; j < len; j += 4) {
                 uint32_t wd = 0;
                 const uint32_t m = std::min<uint32_t>(4, len - j);
                 for (uint32_t r = 0; r < m; ++r) wd |= ((uint32_t)(uint8_t)src[j + r] << 3) << (8 * r);
-                base[(size_t)(j / 4) * SWG_BIN + s] = wd;
+                base[(size_t)(j / 4) * SWG_BIN + SWG_BIN_COLUMN((uint32_t)s)] = wd;
             }
         }
     }

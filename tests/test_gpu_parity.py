@@ -12,7 +12,14 @@ pytestmark = pytest.mark.gpu
 def _setup(ctx, g):
     ctx.set_scoring(g["sub"], int(g["gaps"][0]), int(g["gaps"][1]))
     ctx.set_query(g["query"])
-    for k in ("force_bits", "cols_per_wave", "max_waves", "workgroups"):
+    _reset_options(ctx)
+
+
+OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "workgroups")
+
+
+def _reset_options(ctx):
+    for k in OPTIONS:
         ctx.set_option(k, 0)
 
 
@@ -20,10 +27,16 @@ def _truth(g):
     return g["oracle32"]
 
 
+@pytest.mark.parametrize("engine", [1, 2])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_through_search(swg, ctx, name):
+def test_golden_through_search(swg, ctx, name, engine):
     g = load_golden(name)
     _setup(ctx, g)
+    gaps_ok = g["gaps"][0] <= 0 and g["gaps"][1] <= 0
+    if gaps_ok:
+        ctx.set_option("engine", engine)     # 1 systolic, 2 diagonal (int16 path only)
+    elif engine == 2:
+        pytest.skip("int32 path has one engine")
     db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
     scores, hits, st = ctx.search(db, k=10)
     assert np.array_equal(scores, _truth(g)), (name, st)
@@ -31,8 +44,9 @@ def test_golden_through_search(swg, ctx, name):
         assert np.array_equal(scores, g["ref16"].astype(np.int32))
     best = sorted(((-int(s), i) for i, s in enumerate(_truth(g))))[:10]
     assert hits == [(-s, i) for s, i in best]
-    gaps_ok = g["gaps"][0] <= 0 and g["gaps"][1] <= 0
     assert st["path_bits"] == (16 if gaps_ok else 32)
+    if gaps_ok:
+        assert st["engine"] == engine
     assert st["cells"] == len(g["query"]) * len(g["flat"])
     db.close()
 
@@ -74,12 +88,34 @@ def test_overflow_is_detected_and_rescored(swg, ctx):
     db.close()
 
 
+@pytest.mark.parametrize("cols,group,waves", [(24, 16, 16), (12, 32, 16), (8, 64, 16), (12, 64, 8), (16, 16, 4),
+                                              (32, 64, 12), (8, 16, 4), (8, 32, 8), (24, 64, 4)])
+def test_diagonal_geometry_does_not_change_scores(swg, ctx, cols, group, waves):
+    """Columns per lane, lanes per sequence pair, occupancy and the number of query passes
+    (1 .. 24 here) are invisible in the result of the diagonal engine."""
+    for name in ("blosum62_lq367", "blosum62_lq3000", "pam250_partial_lanes", "blosum62_tiny_db",
+                 "pam250_overflow_w"):
+        g = load_golden(name)
+        _setup(ctx, g)
+        ctx.set_option("engine", 2)
+        ctx.set_option("cols_per_wave", cols)
+        ctx.set_option("group_lanes", group)
+        ctx.set_option("max_waves", waves)
+        db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+        scores, _, st = ctx.search(db)
+        assert np.array_equal(scores, g["oracle32"]), (name, cols, group, waves, st)
+        assert (st["engine"], st["cols_per_wave"], st["group_lanes"], st["waves"]) == (2, cols, group, waves)
+        assert st["passes"] == -(-len(g["query"]) // (cols * group))
+        db.close()
+
+
 @pytest.mark.parametrize("cols,maxw", [(32, 0), (16, 0), (48, 0), (32, 1), (32, 2), (16, 3), (32, 5)])
 def test_geometry_does_not_change_scores(swg, ctx, cols, maxw):
     """Strip width, wave count and the number of query passes are invisible in the result."""
     for name in ("blosum62_lq367", "blosum62_lq3000", "pam250_partial_lanes", "blosum62_tiny_db"):
         g = load_golden(name)
         _setup(ctx, g)
+        ctx.set_option("engine", 1)
         ctx.set_option("cols_per_wave", cols)
         ctx.set_option("max_waves", maxw)
         db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
@@ -112,13 +148,18 @@ def test_random_database_matches_oracle(swg, ctx, orc):
     flat, off = swg.synth_db(0x5EED0002, 3000)
     ctx.set_scoring(sc, -2, -1)
     ctx.set_query(q)
-    for k in ("force_bits", "cols_per_wave", "max_waves", "workgroups"):
-        ctx.set_option(k, 0)
+    _reset_options(ctx)
     want = orc.score_db(q, flat, off, sc.table(), -2, -1)
     db = swg.Database(flat, off).upload(ctx)
     scores, hits, st = ctx.search(db, k=100)
     assert np.array_equal(scores, want)
     assert hits == orc.topk(want, 100)
+    for engine, few in ((1, 0), (2, 0), (2, 3)):
+        ctx.set_option("engine", engine)
+        ctx.set_option("workgroups", few)        # few workgroups: long streams of many pairs
+        sc_e, _, st_e = ctx.search(db)
+        assert st_e["engine"] == engine and np.array_equal(sc_e, want), st_e
+    _reset_options(ctx)
     # unsorted input order must not matter: shuffle, search, compare per sequence
     rng = np.random.default_rng(5)
     perm = rng.permutation(len(off) - 1)
@@ -152,8 +193,7 @@ def test_high_similarity_rescore_matches_oracle(swg, ctx, orc):
     flat, off, planted = swg.synth_db(0x5EED0005, 600, query=q, fraction=0.02, subst=0.05)
     ctx.set_scoring(sc, -2, -1)
     ctx.set_query(q)
-    for k in ("force_bits", "cols_per_wave", "max_waves", "workgroups"):
-        ctx.set_option(k, 0)
+    _reset_options(ctx)
     want = orc.score_db(q, flat, off, sc.table(), -2, -1)
     assert planted >= 3 and (want > 32767).sum() == planted
     db = swg.Database(flat, off).upload(ctx)
@@ -161,6 +201,9 @@ def test_high_similarity_rescore_matches_oracle(swg, ctx, orc):
     assert np.array_equal(scores, want)
     assert st["n_rescored"] == planted and st["passes"] > 1
     assert hits == orc.topk(want, 20)
+    ctx.set_option("engine", 1)
+    scores1, _, st1 = ctx.search(db)
+    assert st1["engine"] == 1 and np.array_equal(scores1, want)
     db.close()
 
 
