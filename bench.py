@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 systolic, 2 diagonal")
     ap.add_argument("--group", type=int, default=0, help="diagonal engine: lanes per sequence pair")
+    ap.add_argument("--long-split", type=int, default=0, help="-1 off, 0 auto, else rows threshold of the long class")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
@@ -97,6 +98,7 @@ def main():
     ctx.set_option("workgroups", args.workgroups)
     ctx.set_option("engine", args.engine)
     ctx.set_option("group_lanes", args.group)
+    ctx.set_option("long_split", args.long_split)
     db = swg.Database(flat, off).upload(ctx)
     residues = int(db.residues)
 
@@ -174,7 +176,8 @@ def main():
                 "cols_per_wave": last["cols_per_wave"], "waves": last["waves"], "passes": last["passes"],
                 "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
                 "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
-                "streams": last["streams"],
+                "streams": last["streams"], "long_pairs": last["long_pairs"],
+                "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],
                 "cells_padded_over_real": round(last["cells_padded"] / max(1, last["cells"]), 4),
             },
             "roofline": {

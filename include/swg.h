@@ -78,6 +78,10 @@ typedef struct swg_stats {
     int32_t engine;         /* 1 systolic (waves chained over the query), 2 diagonal (lane groups) */
     int32_t group_lanes;    /* diagonal engine: lanes sharing one pair of sequences (16/32/64) */
     int32_t streams;        /* diagonal engine: lane groups working in parallel */
+    int32_t long_pairs;     /* diagonal engine: longest pairs run as their own class, 64 lanes each */
+    int32_t long_cols_per_lane;
+    int32_t long_streams;
+    int32_t reserved;
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */
@@ -95,6 +99,7 @@ int swg_abi_version(void);
  * "cols_per_wave" (0 auto | query columns a lane keeps in registers, multiple of 4),
  * "max_waves" (0 auto | systolic: waves chained over the query, 1..16; diagonal:
  * waves per workgroup, multiple of 4), "group_lanes" (0 auto | 16 | 32 | 64),
+ * "long_split" (-1 off | 0 auto | rows above which a pair joins the long class),
  * "workgroups" (0 auto). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 

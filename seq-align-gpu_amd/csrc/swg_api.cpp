@@ -82,6 +82,7 @@ extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, dev));
         ctx->n_cu = prop.multiProcessorCount;
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         for (auto &ev : ctx->ev) HIP_TRY(ctx, hipEventCreate(&ev));
         HIP_TRY(ctx, hipMalloc(&ctx->d_sub, 32 * 32));
         return SWG_OK;
@@ -107,6 +108,7 @@ extern "C" void swg_destroy(swg_ctx *ctx)
     (void)hipFree(ctx->d_scratch);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -130,6 +132,9 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         if (value != 0 && value != 16 && value != 32 && value != 64)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "group_lanes must be 0, 16, 32 or 64");
         ctx->opt_group = value;
+    } else if (!strcmp(key, "long_split")) {
+        if (value < -1) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "long_split must be -1 (off), 0 (auto) or a row count");
+        ctx->opt_long_split = value;
     } else if (!strcmp(key, "workgroups")) {
         if (value < 0) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "workgroups must be >= 0");
         ctx->opt_workgroups = value;
@@ -195,12 +200,16 @@ void swg_db_release_device(swg_db *db)
     (void)hipFree(db->d_list);
     (void)hipFree(db->d_counters);
     (void)hipFree(db->d_keys);
-    (void)hipFree(db->diag.d_tok);
-    (void)hipFree(db->diag.d_stream_off);
-    (void)hipFree(db->diag.d_stream_pairs);
-    (void)hipFree(db->diag.d_stream_pair_off);
-    (void)hipFree(db->diag.d_scratch);
-    db->diag = SwgDiagLayout();
+    (void)hipFree(db->d_hist);
+    db->d_hist = nullptr;
+    for (SwgDiagLayout &L : db->diag) {
+        (void)hipFree(L.d_tok);
+        (void)hipFree(L.d_stream_off);
+        (void)hipFree(L.d_stream_pairs);
+        (void)hipFree(L.d_stream_pair_off);
+        (void)hipFree(L.d_scratch);
+        L = SwgDiagLayout();
+    }
     db->d_packed = nullptr;
     db->d_bin_off = nullptr;
     db->d_bin_nblk = nullptr;
@@ -227,6 +236,8 @@ extern "C" int swg_db_upload(swg_ctx *ctx, swg_db *db)
         HIP_TRY(ctx, hipMalloc(&db->d_scores, std::max<size_t>(4, ns * 4)));
         HIP_TRY(ctx, hipMalloc(&db->d_list, std::max<size_t>(4, ns * 4)));
         HIP_TRY(ctx, hipMalloc(&db->d_counters, 64));
+        HIP_TRY(ctx, hipMalloc(&db->d_keys, SWG_TOPK_CAND_CAP * 8));
+        HIP_TRY(ctx, hipMalloc(&db->d_hist, 4096 * 4));
         if (nb) {
             HIP_TRY(ctx, hipMemcpyAsync(db->d_packed, db->packed.data(), db->packed.size() * 4,
                                         hipMemcpyHostToDevice, ctx->stream));
@@ -315,11 +326,13 @@ static int ensure_profile(swg_ctx *ctx, const Plan &pl)
 
 // Stream layout of the diagonal engine for this database at this stream count,
 // built on the host and kept resident until the geometry changes.
-static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, const SwgDiagPlan &pl)
+static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, int cls, const SwgDiagPlan &pl, uint64_t pair_begin,
+                              uint64_t pair_end)
 {
-    SwgDiagLayout &L = db->diag;
+    SwgDiagLayout &L = db->diag[cls];
     const uint32_t spw = (uint32_t)(pl.W * (64 / pl.G));
-    if (L.n_streams != pl.n_streams || L.streams_per_wg != spw || !L.d_tok) {
+    if (L.n_streams != pl.n_streams || L.streams_per_wg != spw || L.pair_begin != pair_begin ||
+        L.pair_end != pair_end || !L.d_tok) {
         (void)hipFree(L.d_tok);
         (void)hipFree(L.d_stream_off);
         (void)hipFree(L.d_stream_pairs);
@@ -327,7 +340,7 @@ static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, const SwgDiagPlan &pl)
         (void)hipFree(L.d_scratch);
         L = SwgDiagLayout();
         try {
-            swg_build_diag_layout(db, pl.n_streams, spw, &L);
+            swg_build_diag_layout(db, pair_begin, pair_end, pl.n_streams, spw, &L);
             L.streams_per_wg = spw;
         } catch (const std::bad_alloc &) {
             L = SwgDiagLayout();
@@ -338,10 +351,12 @@ static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, const SwgDiagPlan &pl)
         HIP_TRY(ctx, hipMalloc(&L.d_stream_off, (S + 1) * 8));
         HIP_TRY(ctx, hipMalloc(&L.d_stream_pairs, std::max<size_t>(4, L.stream_pairs.size() * 4)));
         HIP_TRY(ctx, hipMalloc(&L.d_stream_pair_off, (S + 1) * 4));
-        HIP_TRY(ctx, hipMemcpyAsync(L.d_tok, L.tok.data(), L.tok.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!L.tok.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(L.d_tok, L.tok.data(), L.tok.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(L.d_stream_off, L.stream_off.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(L.d_stream_pairs, L.stream_pairs.data(), L.stream_pairs.size() * 4,
-                                    hipMemcpyHostToDevice, ctx->stream));
+        if (!L.stream_pairs.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(L.d_stream_pairs, L.stream_pairs.data(), L.stream_pairs.size() * 4,
+                                        hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(L.d_stream_pair_off, L.stream_pair_off.data(), (S + 1) * 4,
                                     hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -355,6 +370,89 @@ static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, const SwgDiagPlan &pl)
         L.d_scratch_rows = L.total_blocks * 4;
     }
     return SWG_OK;
+}
+
+// The diagonal engine's work split: class 0 = the bulk of the pairs, class 1 = the few
+// longest ones, which would otherwise be the serial tail of the whole search.  The long
+// class runs beside the bulk on a second HIP stream with 64 lanes per pair and as few
+// columns per lane as cover the query, i.e. with the shortest possible chain per row.
+struct DiagWork {
+    int n_classes = 0;
+    SwgDiagPlan plan[2];
+    uint64_t pair_begin[2] = {0, 0}, pair_end[2] = {0, 0};
+};
+
+static int plan_diag_work(swg_ctx *ctx, const swg_db *db, size_t lq, DiagWork *wk)
+{
+    const uint64_t n_pairs = swg_db_pair_count(db);
+    uint64_t longest = 0;
+    const uint64_t rows_all = swg_db_pair_rows(db, 0, n_pairs, &longest);
+    SwgDiagPlan all;
+    if (!swg_plan_diag(lq, n_pairs, rows_all, longest, ctx->n_cu, ctx->opt_cols, ctx->opt_group,
+                       ctx->opt_max_waves, &all))
+        return 0;
+    wk->n_classes = 1;
+    wk->plan[0] = all;
+    wk->pair_begin[0] = 0;
+    wk->pair_end[0] = n_pairs;
+    if (ctx->opt_long_split < 0 || ctx->opt_workgroups > 0) return 1;
+    // a pair is "long" when it alone is a large part of what one stream gets
+    uint64_t thr = ctx->opt_long_split > 0 ? (uint64_t)ctx->opt_long_split
+                                           : (uint64_t)(0.5 * (double)rows_all / (double)all.n_streams);
+    thr = std::max<uint64_t>(thr, 64);
+    if (longest <= thr) return 1;
+    const uint64_t n_long = swg_db_pairs_longer_than(db, thr);
+    if (n_long == 0 || n_long * 4 > n_pairs) return 1;
+    // long class: 64 lanes per pair, the narrowest instantiation that covers the query
+    // in the fewest passes
+    SwgDiagPlan lp;
+    bool ok = false;
+    {
+        uint64_t l1 = 0;
+        const uint64_t rows_long = swg_db_pair_rows(db, 0, n_long, &l1);
+        int best_cost = 1 << 30;
+        for (int v = 0; v < swg_num_diag_variants(); ++v) {
+            const SwgKernelInfo info = swg_diag_variant_info(v);
+            const size_t cols = 64u * (size_t)info.K;
+            if (cols * 64 > 160 * 1024) continue;
+            const int npass = (int)((lq + cols - 1) / cols);
+            const int cost = npass * (11 * info.K + 14);
+            if (cost < best_cost) {
+                best_cost = cost;
+                lp.variant = v;
+                lp.K = info.K;
+                lp.G = 64;
+                lp.npass = npass;
+                lp.W = 4;
+                lp.lds_bytes = cols * 64;
+                ok = true;
+            }
+        }
+        if (ok) {
+            // about two pairs per stream, at most one 4-wave workgroup per CU... the work is small
+            uint64_t streams = std::max<uint64_t>(1, std::min<uint64_t>((n_long + 1) / 2, (uint64_t)ctx->n_cu * 4));
+            streams = (streams + 3) / 4 * 4;
+            lp.n_streams = (uint32_t)streams;
+            lp.workgroups = (int)(streams / 4);
+            lp.est_ms = 0;
+            (void)rows_long;
+        }
+    }
+    if (!ok) return 1;
+    uint64_t l2 = 0;
+    const uint64_t rows_bulk = swg_db_pair_rows(db, n_long, n_pairs, &l2);
+    SwgDiagPlan bulk;
+    if (!swg_plan_diag(lq, n_pairs - n_long, rows_bulk, l2, ctx->n_cu, ctx->opt_cols, ctx->opt_group,
+                       ctx->opt_max_waves, &bulk))
+        return 1;
+    wk->n_classes = 2;
+    wk->plan[0] = bulk;
+    wk->pair_begin[0] = n_long;
+    wk->pair_end[0] = n_pairs;
+    wk->plan[1] = lp;
+    wk->pair_begin[1] = 0;
+    wk->pair_end[1] = n_long;
+    return 2;
 }
 
 static int ensure_scratch(swg_ctx *ctx, size_t dwords)
@@ -431,22 +529,21 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     int rc = make_plan(ctx, bits, bits == 16 ? n_bins : n_bins * 2, &main_pl);
     if (rc != SWG_OK && !(bits == 16 && ctx->opt_engine != 1)) return rc;
     // int16: the diagonal engine unless the systolic one is asked for
-    SwgDiagPlan dpl;
+    DiagWork wk;
     bool use_diag = false;
     if (bits == 16 && ctx->opt_engine != 1) {
-        uint64_t longest_rows = 0;
-        const uint64_t pair_rows = swg_db_pair_rows(db, &longest_rows);
-        use_diag = swg_plan_diag(lq, (db->n_local + 1) / 2, pair_rows, longest_rows, ctx->n_cu, ctx->opt_cols,
-                                 ctx->opt_group, ctx->opt_max_waves, &dpl);
+        use_diag = plan_diag_work(ctx, db, lq, &wk) > 0;
         if (!use_diag && ctx->opt_engine == 2)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
         if (use_diag && ctx->opt_workgroups > 0) {
-            const uint64_t per_wg = (uint64_t)dpl.W * (64 / dpl.G);
-            dpl.workgroups = (int)std::min<long>(ctx->opt_workgroups, dpl.workgroups);
-            dpl.n_streams = (uint32_t)((uint64_t)dpl.workgroups * per_wg);
+            SwgDiagPlan &d0 = wk.plan[0];
+            const uint64_t per_wg = (uint64_t)d0.W * (64 / d0.G);
+            d0.workgroups = (int)std::min<long>(ctx->opt_workgroups, d0.workgroups);
+            d0.n_streams = (uint32_t)((uint64_t)d0.workgroups * per_wg);
         }
         if (!use_diag && rc != SWG_OK) return rc;
     }
+    const SwgDiagPlan &dpl = wk.plan[0];
     // can an int16 score saturate at all?  score <= min(lq, longest) * max(S)
     int smax = 0;
     for (int a = 0; a < 32; ++a)
@@ -461,10 +558,15 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         if (rc != SWG_OK) return rc;
     }
     if (use_diag) {
-        rc = ensure_diag_layout(ctx, const_cast<swg_db *>(db), dpl);
-        if (rc != SWG_OK) return rc;
-        rc = ensure_profile_cols(ctx, 0, (uint32_t)(dpl.npass * dpl.G * dpl.K), 2,
-                                 (1ull << 31) ^ ((uint64_t)dpl.K << 20) ^ ((uint64_t)dpl.G << 12) ^ (uint64_t)dpl.npass);
+        uint32_t ncols = 0;
+        uint64_t geom = 1ull << 31;
+        for (int c = 0; c < wk.n_classes; ++c) {
+            rc = ensure_diag_layout(ctx, const_cast<swg_db *>(db), c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
+            if (rc != SWG_OK) return rc;
+            ncols = std::max<uint32_t>(ncols, (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
+        }
+        geom ^= ncols; // both classes slice the same [col/4][32][4] profile
+        rc = ensure_profile_cols(ctx, 0, ncols, 2, geom);
     } else {
         rc = ensure_profile(ctx, main_pl);
     }
@@ -495,28 +597,43 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     if (use_diag) {
-        SwgDiagParams d;
-        memset(&d, 0, sizeof d);
-        d.tok = db->diag.d_tok;
-        d.stream_off = db->diag.d_stream_off;
-        d.stream_pairs = db->diag.d_stream_pairs;
-        d.stream_pair_off = db->diag.d_stream_pair_off;
-        d.n_streams = db->diag.n_streams;
-        d.profile = ctx->d_profile[0];
-        d.scores = db->d_scores;
-        d.scratch = db->diag.d_scratch;
-        d.npass = (uint32_t)dpl.npass;
-        d.G = (uint32_t)dpl.G;
         const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
-        d.go = g | (g << 16);
-        d.ge = e | (e << 16);
-        // streams that hold little more than one very long pair are the critical path:
-        // their wavefronts get issue priority over the ones they share a SIMD with
-        const double mean_blocks = (double)db->diag.total_blocks / std::max<uint32_t>(1, db->diag.n_streams);
-        d.prio_blocks = (double)db->diag.max_stream_blocks > 1.1 * mean_blocks
-                            ? (uint32_t)(0.75 * (double)db->diag.max_stream_blocks)
-                            : 0xFFFFFFFFu;
-        HIP_TRY(ctx, swg_launch_diag(dpl.variant, dpl.npass > 1, dpl.W, dpl.workgroups, dpl.lds_bytes, d, s));
+        if (wk.n_classes == 2) {
+            // fork: the long pairs start first, on their own stream, beside the bulk
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[6], s));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
+        }
+        for (int c = wk.n_classes - 1; c >= 0; --c) {
+            const SwgDiagLayout &L = db->diag[c];
+            const SwgDiagPlan &pl = wk.plan[c];
+            SwgDiagParams d;
+            memset(&d, 0, sizeof d);
+            d.tok = L.d_tok;
+            d.stream_off = L.d_stream_off;
+            d.stream_pairs = L.d_stream_pairs;
+            d.stream_pair_off = L.d_stream_pair_off;
+            d.n_streams = L.n_streams;
+            d.profile = ctx->d_profile[0];
+            d.scores = db->d_scores;
+            d.scratch = L.d_scratch;
+            d.npass = (uint32_t)pl.npass;
+            d.G = (uint32_t)pl.G;
+            d.go = g | (g << 16);
+            d.ge = e | (e << 16);
+            // wavefronts on the critical path get issue priority over the ones they
+            // share a SIMD with: all of the long class; in the bulk, streams that hold
+            // little more than one very long pair
+            const double mean_blocks = (double)L.total_blocks / std::max<uint32_t>(1, L.n_streams);
+            d.prio_blocks = c == 1 ? 0u
+                            : (double)L.max_stream_blocks > 1.1 * mean_blocks ? (uint32_t)(0.75 * (double)L.max_stream_blocks)
+                                                                              : 0xFFFFFFFFu;
+            HIP_TRY(ctx, swg_launch_diag(pl.variant, pl.npass > 1, pl.W, pl.workgroups, pl.lds_bytes, d,
+                                         c == 1 ? ctx->stream2 : s));
+        }
+        if (wk.n_classes == 2) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[7], 0));
+        }
     } else {
         p.profile = ctx->d_profile[bits == 16 ? 0 : 1];
         p.queue = db->d_counters + 0;
@@ -552,24 +669,51 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
 
-    // read-out: scores of this shard, then top-K (host selection in this round)
+    // top-K on the device unless every score goes to the host anyway
+    const bool dev_topk = k > 0 && scores_out == nullptr && k <= SWG_TOPK_CAND_CAP / 2;
+    if (dev_topk)
+        HIP_TRY(ctx, swg_launch_topk(db->d_scores, db->d_order, (uint32_t)n_slots, (uint32_t)k, db->d_hist,
+                                     db->d_counters + 4, db->d_keys, SWG_TOPK_CAND_CAP, db->d_counters + 3, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+
+    // read-out
     std::vector<int32_t> h_scores;
-    uint32_t h_counters[4] = {0, 0, 0, 0};
-    const bool need_scores = scores_out != nullptr || k > 0;
+    std::vector<uint64_t> h_cand;
+    uint32_t h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool need_scores = scores_out != nullptr || (k > 0 && !dev_topk);
+    const size_t first_chunk = std::min<size_t>(SWG_TOPK_CAND_CAP, 2 * k + 64);
+    if (dev_topk) {
+        h_cand.resize(SWG_TOPK_CAND_CAP);
+        HIP_TRY(ctx, hipMemcpyAsync(h_cand.data(), db->d_keys, first_chunk * 8, hipMemcpyDeviceToHost, s));
+    }
     if (need_scores) {
         h_scores.resize(n_slots);
         HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipMemcpyAsync(h_counters, db->d_counters, sizeof h_counters, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    bool cand_ok = dev_topk && h_counters[5] == 0 && h_counters[3] <= SWG_TOPK_CAND_CAP;
+    if (cand_ok && h_counters[3] > first_chunk) {
+        HIP_TRY(ctx, hipMemcpyAsync(h_cand.data() + first_chunk, db->d_keys + first_chunk,
+                                    (h_counters[3] - first_chunk) * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    if (dev_topk && !cand_ok) { // threshold beyond the histogram or too many ties: select on the host
+        h_scores.resize(n_slots);
+        HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        need_scores = true;
+    }
 
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
     st.fill_ms = ms;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     st.rescore_ms = may_saturate ? ms : 0.0;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
     st.total_ms = ms;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+    const double topk_dev_ms = ms;
     st.n_rescored = h_counters[1];
     st.path_bits = bits;
     if (use_diag) {
@@ -579,8 +723,15 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         st.waves = dpl.W;
         st.passes = dpl.npass;
         st.workgroups = dpl.workgroups;
-        st.streams = (int32_t)db->diag.n_streams;
-        st.cells_padded = 2ull * dpl.npass * dpl.G * dpl.K * db->diag.total_blocks * 4ull;
+        st.streams = (int32_t)db->diag[0].n_streams;
+        st.cells_padded = 2ull * dpl.npass * dpl.G * dpl.K * db->diag[0].total_blocks * 4ull;
+        if (wk.n_classes == 2) {
+            const SwgDiagPlan &lp = wk.plan[1];
+            st.long_pairs = (int32_t)(wk.pair_end[1] - wk.pair_begin[1]);
+            st.long_cols_per_lane = lp.K;
+            st.long_streams = (int32_t)db->diag[1].n_streams;
+            st.cells_padded += 2ull * lp.npass * lp.G * lp.K * db->diag[1].total_blocks * 4ull;
+        }
     } else {
         st.engine = 1;
         st.cols_per_wave = main_pl.K;
@@ -599,17 +750,21 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     }
     if (k > 0) {
         std::vector<uint64_t> keys;
-        keys.reserve(db->n_local);
-        for (size_t i = 0; i < n_slots; ++i) {
-            const uint32_t oi = db->order[i];
-            if (oi != 0xFFFFFFFFu) keys.push_back(swg_hit_key(h_scores[i], oi));
+        if (cand_ok) {
+            keys.assign(h_cand.begin(), h_cand.begin() + h_counters[3]);
+        } else {
+            keys.reserve(db->n_local);
+            for (size_t i = 0; i < n_slots; ++i) {
+                const uint32_t oi = db->order[i];
+                if (oi != 0xFFFFFFFFu) keys.push_back(swg_hit_key(h_scores[i], oi));
+            }
         }
         const size_t m = std::min(k, keys.size());
         std::partial_sort(keys.begin(), keys.begin() + m, keys.end(), std::greater<uint64_t>());
         for (size_t i = 0; i < m; ++i) swg_key_hit(keys[i], &topk_out[i]);
         if (n_hits) *n_hits = m;
     }
-    st.topk_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    st.topk_ms = topk_dev_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (stats) *stats = st;
     return SWG_OK;
 }

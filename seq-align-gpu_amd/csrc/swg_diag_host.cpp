@@ -12,18 +12,29 @@
 // packed-int16 / DPP / v_perm wave-instruction when `wps` waves share it.
 static const double kCyclesPerInstr[5] = {0.0, 6.8, 5.1, 4.8, 4.56};
 
-uint64_t swg_db_pair_rows(const swg_db *db, uint64_t *longest_rows)
+uint64_t swg_db_pair_count(const swg_db *db) { return (db->n_local + 1) / 2; }
+
+uint64_t swg_db_pair_rows(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint64_t *longest_rows)
 {
-    const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     uint64_t total = 0, longest = 0;
-    for (size_t s = 0; s < n_slots; s += 2) {
-        if (db->order[s] == 0xFFFFFFFFu) break;
-        const uint64_t r = 2ull + db->lens[s];
+    for (uint64_t p = pair_begin; p < pair_end; ++p) {
+        const uint64_t r = 2ull + db->lens[2 * p];
         total += r;
         longest = std::max(longest, r);
     }
     if (longest_rows) *longest_rows = longest;
     return total;
+}
+
+uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)
+{
+    // pairs are sorted by length, longest first: binary search the prefix
+    uint64_t lo = 0, hi = swg_db_pair_count(db);
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (2ull + db->lens[2 * mid] > rows) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 bool swg_plan_diag(size_t lq, uint64_t n_pairs, uint64_t pair_rows_total, uint64_t longest_rows, int n_cu,
@@ -84,14 +95,13 @@ bool swg_plan_diag(size_t lq, uint64_t n_pairs, uint64_t pair_rows_total, uint64
     return found;
 }
 
-void swg_build_diag_layout(const swg_db *db, uint32_t n_streams, uint32_t streams_per_wg, SwgDiagLayout *L)
+void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
+                           uint32_t streams_per_wg, SwgDiagLayout *L)
 {
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
-    size_t n_pairs = 0;
-    for (size_t s = 0; s < n_slots; s += 2) {
-        if (db->order[s] == 0xFFFFFFFFu) break;
-        ++n_pairs;
-    }
+    const size_t n_pairs = (size_t)(pair_end - pair_begin);
+    L->pair_begin = pair_begin;
+    L->pair_end = pair_end;
     L->n_streams = n_streams;
     // longest-processing-time-first: pairs are already sorted by length (descending)
     std::vector<uint32_t> owner(n_pairs);
@@ -111,12 +121,13 @@ void swg_build_diag_layout(const swg_db *db, uint32_t n_streams, uint32_t stream
             const uint32_t s = (h % n_wgs) * spw + (h / n_wgs);
             return s < n_streams ? s : h; // (n_streams is a multiple of spw in practice)
         };
-        for (size_t p = 0; p < n_pairs; ++p) {
+        for (size_t q = 0; q < n_pairs; ++q) {
+            const size_t p = pair_begin + q;
             const uint64_t blocks = (2ull + db->lens[2 * p] + 3) / 4;
             item it = heap.top();
             heap.pop();
             const uint32_t s = phys(it.second);
-            owner[p] = s;
+            owner[q] = s;
             load[s] = it.first + blocks;
             count[s]++;
             heap.push(item(it.first + blocks, it.second));
@@ -133,13 +144,13 @@ void swg_build_diag_layout(const swg_db *db, uint32_t n_streams, uint32_t stream
     L->stream_pairs.assign(n_pairs, 0);
     {
         std::vector<uint32_t> fill(n_streams, 0);
-        for (size_t p = 0; p < n_pairs; ++p) {
-            const uint32_t s = owner[p];
-            L->stream_pairs[L->stream_pair_off[s] + fill[s]++] = (uint32_t)p;
+        for (size_t q = 0; q < n_pairs; ++q) {
+            const uint32_t s = owner[q];
+            L->stream_pairs[L->stream_pair_off[s] + fill[s]++] = (uint32_t)(pair_begin + q);
         }
     }
     uint64_t rows_total = 0;
-    for (size_t p = 0; p < n_pairs; ++p) rows_total += 2ull + db->lens[2 * p];
+    for (size_t p = pair_begin; p < pair_end; ++p) rows_total += 2ull + db->lens[2 * p];
     L->pair_rows_total = rows_total;
     L->tok.assign(L->total_blocks * 2, 0u);
     uint16_t *base = reinterpret_cast<uint16_t *>(L->tok.data()); // one 16-bit token per row

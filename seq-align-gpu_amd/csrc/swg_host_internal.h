@@ -12,6 +12,7 @@
 struct SwgDiagLayout {
     uint32_t n_streams = 0;
     uint32_t streams_per_wg = 0;
+    uint64_t pair_begin = 0, pair_end = 0; // pairs of the sorted order laid out here
     uint64_t total_blocks = 0;      // 4-row token blocks over all streams
     uint64_t max_stream_blocks = 0;
     uint64_t pair_rows_total = 0;   // sum over pairs of (2 + longer length), unpadded
@@ -43,7 +44,7 @@ struct swg_db {
     std::vector<uint32_t> packed;   // residue dwords (bins, systolic engine)
     std::vector<uint8_t> codes;     // residue bytes (index<<3) by sorted rank, back to back
     std::vector<uint64_t> code_off; // [n_bins*128+1]
-    SwgDiagLayout diag;             // stream layout of the diagonal engine (built on demand)
+    SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs
     // device image (valid after swg_db_upload)
     int device = -1;
     uint32_t *d_packed = nullptr;
@@ -53,12 +54,14 @@ struct swg_db {
     int32_t *d_scores = nullptr;  // [n_bins*128]
     uint32_t *d_list = nullptr;   // [n_bins*128] saturated slot ids
     uint32_t *d_counters = nullptr; // [0] work queue, [1] saturated count, [2] queue of rescore
-    uint64_t *d_keys = nullptr;   // [n_bins*128] top-K keys
+    uint64_t *d_keys = nullptr;   // top-K candidate keys (SWG_TOPK_CAND_CAP)
+    uint32_t *d_hist = nullptr;   // top-K score histogram
 };
 
 struct swg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // long-pair kernel runs beside the bulk kernel
     int n_cu = 0;
     std::string err;
     // scoring
@@ -68,7 +71,7 @@ struct swg_ctx {
     // query
     std::vector<int8_t> query;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0;
     // device state
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;
@@ -79,7 +82,7 @@ struct swg_ctx {
     uint64_t epoch = 1;               // bumps whenever scoring or query change
     uint32_t *d_scratch = nullptr;
     size_t d_scratch_cap = 0; // dwords
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 int swg_set_global_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -97,5 +100,10 @@ struct SwgDiagPlan {
 // geometry for one query length on one device; returns false if the diagonal engine cannot run it
 bool swg_plan_diag(size_t lq, uint64_t n_pairs, uint64_t pair_rows_total, uint64_t longest_rows, int n_cu,
                    long opt_cols, long opt_group, long opt_waves, SwgDiagPlan *out);
-void swg_build_diag_layout(const swg_db *db, uint32_t n_streams, uint32_t streams_per_wg, SwgDiagLayout *out);
-uint64_t swg_db_pair_rows(const swg_db *db, uint64_t *longest_rows);
+void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
+                           uint32_t streams_per_wg, SwgDiagLayout *out);
+uint64_t swg_db_pair_count(const swg_db *db);
+// rows (2 reset rows + longer length) of the pairs [pair_begin, pair_end): total and longest
+uint64_t swg_db_pair_rows(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint64_t *longest_rows);
+// how many leading (longest) pairs have more than `rows` rows
+uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows);

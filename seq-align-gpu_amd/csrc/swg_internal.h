@@ -81,3 +81,10 @@ hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots,
                                         uint32_t *d_list, uint32_t *d_count,
                                         hipStream_t stream);
+
+// Device top-K (see swg_kernels.hip): after the call d_thr[1] == 0 means d_cand[0..min(*d_count,cap))
+// holds every hit with score >= d_thr[0] as 64-bit keys (unsorted); otherwise fall back.
+#define SWG_TOPK_CAND_CAP 8192u
+hipError_t swg_launch_topk(const int32_t *d_scores, const uint32_t *d_order, uint32_t n_slots, uint32_t k,
+                           uint32_t *d_hist, uint32_t *d_thr, uint64_t *d_cand, uint32_t cap, uint32_t *d_count,
+                           hipStream_t stream);

@@ -624,6 +624,103 @@ __global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, 
 }
 
 // ---------------------------------------------------------------------------
+// device top-K: histogram -> threshold -> compaction of the few candidates
+// ---------------------------------------------------------------------------
+// Hits are ordered by (score desc, original index asc) = descending 64-bit key.
+// Scores are small integers, so a 4096-bin histogram finds the score T of the
+// K-th best hit; every entry with score >= T (K plus ties at T) is appended to a
+// candidate list that the host sorts.  Scores >= 4095 share the last bin; if the
+// threshold falls there, or the candidates do not fit, `status` tells the host
+// to fall back to reading all scores.
+#define SWG_TOPK_BINS 4096
+
+__global__ void swg_topk_hist_kernel(const int32_t *scores, const uint32_t *order, uint32_t n, uint32_t *hist)
+{
+    __shared__ uint32_t h[SWG_TOPK_BINS];
+    for (int i = threadIdx.x; i < SWG_TOPK_BINS; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (order[i] == 0xFFFFFFFFu) continue;
+        int v = scores[i];
+        v = v < 0 ? 0 : (v > SWG_TOPK_BINS - 1 ? SWG_TOPK_BINS - 1 : v);
+        atomicAdd(&h[v], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SWG_TOPK_BINS; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// one block of 1024 threads: out[0] = threshold score T, out[1] = status (0 ok, 1 fall back)
+__global__ void swg_topk_threshold_kernel(const uint32_t *hist, uint32_t k, uint32_t cap, uint32_t *out)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    uint32_t b[4], sum = 0;
+    for (int j = 0; j < 4; ++j) {
+        b[j] = hist[4 * t + j];
+        sum += b[j];
+    }
+    part[t] = sum;
+    __syncthreads();
+    // suffix sums: part[t] = entries in bins >= 4t
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t add = (t + d < 1024) ? part[t + d] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    const uint32_t total = part[0];
+    const uint32_t want = k < total ? k : total;
+    const uint32_t above = (t + 1 < 1024) ? part[t + 1] : 0u; // entries in bins >= 4(t+1)
+    if (want > 0 && above < want && part[t] >= want) {
+        uint32_t acc = above;
+        int T = 4 * t;
+        for (int j = 3; j >= 0; --j) {
+            acc += b[j];
+            if (acc >= want) {
+                T = 4 * t + j;
+                break;
+            }
+        }
+        out[0] = (uint32_t)T;
+        out[1] = (T == SWG_TOPK_BINS - 1 || acc > cap) ? 1u : 0u;
+    }
+    if (want == 0 && t == 0) {
+        out[0] = 0u;
+        out[1] = 0u;
+    }
+}
+
+__global__ void swg_topk_compact_kernel(const int32_t *scores, const uint32_t *order, uint32_t n,
+                                        const uint32_t *thr, uint64_t *cand, uint32_t cap, uint32_t *count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || thr[1] != 0u) return;
+    const uint32_t oi = order[i];
+    if (oi == 0xFFFFFFFFu) return;
+    const int v = scores[i];
+    if (v >= (int)thr[0]) {
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < cap) cand[at] = ((uint64_t)(uint32_t)(v < 0 ? 0 : v) << 32) | (uint64_t)(0xFFFFFFFFu - oi);
+    }
+}
+
+hipError_t swg_launch_topk(const int32_t *d_scores, const uint32_t *d_order, uint32_t n_slots, uint32_t k,
+                           uint32_t *d_hist, uint32_t *d_thr, uint64_t *d_cand, uint32_t cap, uint32_t *d_count,
+                           hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_hist, 0, SWG_TOPK_BINS * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int blocks = (int)((n_slots + 255) / 256 < 512 ? (n_slots + 255) / 256 : 512);
+    hipLaunchKernelGGL(swg_topk_hist_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, d_scores, d_order,
+                       n_slots, d_hist);
+    hipLaunchKernelGGL(swg_topk_threshold_kernel, dim3(1), dim3(1024), 0, stream, d_hist, k, cap, d_thr);
+    hipLaunchKernelGGL(swg_topk_compact_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, d_scores,
+                       d_order, n_slots, d_thr, d_cand, cap, d_count);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 namespace {

@@ -15,7 +15,7 @@ def _setup(ctx, g):
     _reset_options(ctx)
 
 
-OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "workgroups")
+OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups")
 
 
 def _reset_options(ctx):
@@ -154,11 +154,15 @@ def test_random_database_matches_oracle(swg, ctx, orc):
     scores, hits, st = ctx.search(db, k=100)
     assert np.array_equal(scores, want)
     assert hits == orc.topk(want, 100)
-    for engine, few in ((1, 0), (2, 0), (2, 3)):
+    for engine, few, split in ((1, 0, 0), (2, 0, 0), (2, 3, 0), (2, 0, -1), (2, 0, 1500), (2, 0, 700), (2, 0, 40)):
         ctx.set_option("engine", engine)
         ctx.set_option("workgroups", few)        # few workgroups: long streams of many pairs
+        ctx.set_option("long_split", split)      # off / forced: longest pairs as their own class
         sc_e, _, st_e = ctx.search(db)
         assert st_e["engine"] == engine and np.array_equal(sc_e, want), st_e
+        if split > 0:
+            n_long = int((np.diff(off.astype(np.int64))[::2] + 2 > max(split, 64)).sum())
+            assert st_e["long_pairs"] == (n_long if n_long * 4 <= 1500 else 0)   # never more than a quarter
     _reset_options(ctx)
     # unsorted input order must not matter: shuffle, search, compare per sequence
     rng = np.random.default_rng(5)
@@ -204,6 +208,23 @@ def test_high_similarity_rescore_matches_oracle(swg, ctx, orc):
     ctx.set_option("engine", 1)
     scores1, _, st1 = ctx.search(db)
     assert st1["engine"] == 1 and np.array_equal(scores1, want)
+    db.close()
+
+
+@pytest.mark.parametrize("name", ["pam250_lq128", "blosum62_lq367", "blosum62_tiny_db", "blosum62_lq1",
+                                  "pam250_overflow_w", "blosum62_lq3000"])
+def test_device_topk_matches_oracle_order(swg, ctx, orc, name):
+    """Top-K selected on the device (scores stay in HBM): same hits, same tie order as the
+    oracle's full sort, for K below, around and above the number of sequences, with heavy
+    ties (tiny scores) and with scores beyond the histogram range (host fall-back)."""
+    g = load_golden(name)
+    _setup(ctx, g)
+    db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    n = len(g["offsets"]) - 1
+    for k in (1, 7, 100, n - 1, n, n + 50, 4000):
+        scores, hits, st = ctx.search(db, want_scores=False, k=k)
+        assert scores is None
+        assert hits == orc.topk(g["oracle32"], k), (name, k)
     db.close()
 
 

@@ -1,0 +1,23 @@
+cd $GRAFT_REPO_ROOT
+run() {
+  timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+c=d['config']
+print('$*', '->', d['value'],'GCUPS K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'wgs',c['workgroups'], 'S',c.get('streams'), 'long',c.get('long_pairs'),c.get('long_cols_per_lane'),c.get('long_streams'),'pad', c['cells_padded_over_real'], 'fill', d['kernel_ms']['fill'], 'step', d['ms_per_step'], d['kernel_ms'])
+"
+}
+timeout -k 10 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+run
+run --cols 24 --group 16 --max-waves 8
+run --cols 24 --group 16 --max-waves 8 --long-split 1000
+run --cols 24 --group 16 --max-waves 8 --long-split 1500
+run --cols 24 --group 16 --max-waves 8 --long-split 2500
+run --cols 24 --group 16 --max-waves 8 --long-split -1
+run --cols 24 --group 16 --max-waves 16 --long-split 1500
+run --cols 12 --group 32 --max-waves 12 --long-split 1000
+run --cols 12 --group 32 --max-waves 12 --long-split 1500
+run --config 3
+run --config 3 --cols 32 --group 16 --max-waves 12
+run --config 3 --cols 16 --group 32 --max-waves 16
+run --config 3 --cols 8 --group 64 --max-waves 16
