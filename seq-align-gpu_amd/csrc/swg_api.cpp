@@ -372,89 +372,6 @@ static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, int cls, const SwgDiagPl
     return SWG_OK;
 }
 
-// The diagonal engine's work split: class 0 = the bulk of the pairs, class 1 = the few
-// longest ones, which would otherwise be the serial tail of the whole search.  The long
-// class runs beside the bulk on a second HIP stream with 64 lanes per pair and as few
-// columns per lane as cover the query, i.e. with the shortest possible chain per row.
-struct DiagWork {
-    int n_classes = 0;
-    SwgDiagPlan plan[2];
-    uint64_t pair_begin[2] = {0, 0}, pair_end[2] = {0, 0};
-};
-
-static int plan_diag_work(swg_ctx *ctx, const swg_db *db, size_t lq, DiagWork *wk)
-{
-    const uint64_t n_pairs = swg_db_pair_count(db);
-    uint64_t longest = 0;
-    const uint64_t rows_all = swg_db_pair_rows(db, 0, n_pairs, &longest);
-    SwgDiagPlan all;
-    if (!swg_plan_diag(lq, n_pairs, rows_all, longest, ctx->n_cu, ctx->opt_cols, ctx->opt_group,
-                       ctx->opt_max_waves, &all))
-        return 0;
-    wk->n_classes = 1;
-    wk->plan[0] = all;
-    wk->pair_begin[0] = 0;
-    wk->pair_end[0] = n_pairs;
-    if (ctx->opt_long_split < 0 || ctx->opt_workgroups > 0) return 1;
-    // a pair is "long" when it alone is a large part of what one stream gets
-    uint64_t thr = ctx->opt_long_split > 0 ? (uint64_t)ctx->opt_long_split
-                                           : (uint64_t)(0.5 * (double)rows_all / (double)all.n_streams);
-    thr = std::max<uint64_t>(thr, 64);
-    if (longest <= thr) return 1;
-    const uint64_t n_long = swg_db_pairs_longer_than(db, thr);
-    if (n_long == 0 || n_long * 4 > n_pairs) return 1;
-    // long class: 64 lanes per pair, the narrowest instantiation that covers the query
-    // in the fewest passes
-    SwgDiagPlan lp;
-    bool ok = false;
-    {
-        uint64_t l1 = 0;
-        const uint64_t rows_long = swg_db_pair_rows(db, 0, n_long, &l1);
-        int best_cost = 1 << 30;
-        for (int v = 0; v < swg_num_diag_variants(); ++v) {
-            const SwgKernelInfo info = swg_diag_variant_info(v);
-            const size_t cols = 64u * (size_t)info.K;
-            if (cols * 64 > 160 * 1024) continue;
-            const int npass = (int)((lq + cols - 1) / cols);
-            const int cost = npass * (11 * info.K + 14);
-            if (cost < best_cost) {
-                best_cost = cost;
-                lp.variant = v;
-                lp.K = info.K;
-                lp.G = 64;
-                lp.npass = npass;
-                lp.W = 4;
-                lp.lds_bytes = cols * 64;
-                ok = true;
-            }
-        }
-        if (ok) {
-            // about two pairs per stream, at most one 4-wave workgroup per CU... the work is small
-            uint64_t streams = std::max<uint64_t>(1, std::min<uint64_t>((n_long + 1) / 2, (uint64_t)ctx->n_cu * 4));
-            streams = (streams + 3) / 4 * 4;
-            lp.n_streams = (uint32_t)streams;
-            lp.workgroups = (int)(streams / 4);
-            lp.est_ms = 0;
-            (void)rows_long;
-        }
-    }
-    if (!ok) return 1;
-    uint64_t l2 = 0;
-    const uint64_t rows_bulk = swg_db_pair_rows(db, n_long, n_pairs, &l2);
-    SwgDiagPlan bulk;
-    if (!swg_plan_diag(lq, n_pairs - n_long, rows_bulk, l2, ctx->n_cu, ctx->opt_cols, ctx->opt_group,
-                       ctx->opt_max_waves, &bulk))
-        return 1;
-    wk->n_classes = 2;
-    wk->plan[0] = bulk;
-    wk->pair_begin[0] = n_long;
-    wk->pair_end[0] = n_pairs;
-    wk->plan[1] = lp;
-    wk->pair_begin[1] = 0;
-    wk->pair_end[1] = n_long;
-    return 2;
-}
-
 static int ensure_scratch(swg_ctx *ctx, size_t dwords)
 {
     if (dwords <= ctx->d_scratch_cap) return SWG_OK;
@@ -529,10 +446,11 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     int rc = make_plan(ctx, bits, bits == 16 ? n_bins : n_bins * 2, &main_pl);
     if (rc != SWG_OK && !(bits == 16 && ctx->opt_engine != 1)) return rc;
     // int16: the diagonal engine unless the systolic one is asked for
-    DiagWork wk;
+    SwgDiagWork wk;
     bool use_diag = false;
     if (bits == 16 && ctx->opt_engine != 1) {
-        use_diag = plan_diag_work(ctx, db, lq, &wk) > 0;
+        use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
+                                      ctx->opt_long_split, ctx->opt_workgroups == 0, &wk) > 0;
         if (!use_diag && ctx->opt_engine == 2)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
         if (use_diag && ctx->opt_workgroups > 0) {
@@ -557,6 +475,16 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         ctx->opt_cols = keep_cols;
         if (rc != SWG_OK) return rc;
     }
+    // int32 work (forced / unusual gap scores / re-score of saturated sequences) also runs on
+    // the diagonal engine unless the systolic one is asked for
+    const bool use_diag32 = ctx->opt_engine != 1;
+    const int npass32 = (int)((lq + 64 * SWG_DIAG32_K - 1) / (64 * SWG_DIAG32_K));
+    if (use_diag32 && (bits == 32 || may_saturate)) {
+        rc = ensure_profile_cols(ctx, 1, (uint32_t)(npass32 * 64 * SWG_DIAG32_K), 4, (1ull << 30) ^ (uint64_t)npass32);
+        if (rc != SWG_OK) return rc;
+        const size_t per_wave = ((size_t)db->max_nblk * 4 + 4) * 4; // dwords: one uint4 per stream row
+        if ((rc = ensure_scratch(ctx, npass32 > 1 ? per_wave * 16 * (size_t)ctx->n_cu : 0)) != SWG_OK) return rc;
+    }
     if (use_diag) {
         uint32_t ncols = 0;
         uint64_t geom = 1ull << 31;
@@ -567,16 +495,18 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         }
         geom ^= ncols; // both classes slice the same [col/4][32][4] profile
         rc = ensure_profile_cols(ctx, 0, ncols, 2, geom);
-    } else {
+    } else if (!(bits == 32 && use_diag32)) {
         rc = ensure_profile(ctx, main_pl);
     }
     if (rc != SWG_OK) return rc;
-    if (may_saturate && (rc = ensure_profile(ctx, re_pl)) != SWG_OK) return rc;
+    if (may_saturate && !use_diag32 && (rc = ensure_profile(ctx, re_pl)) != SWG_OK) return rc;
     {
         size_t need = 0;
-        if (!use_diag && main_pl.npass > 1)
+        if (use_diag32 && (bits == 32 || may_saturate) && npass32 > 1)
+            need = ((size_t)db->max_nblk * 4 + 4) * 4 * 16 * (size_t)ctx->n_cu;
+        if (!use_diag && !(bits == 32 && use_diag32) && main_pl.npass > 1)
             need = std::max(need, (size_t)main_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb);
-        if (may_saturate && re_pl.npass > 1)
+        if (may_saturate && !use_diag32 && re_pl.npass > 1)
             need = std::max(need, (size_t)re_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * re_pl.info.nb);
         if ((rc = ensure_scratch(ctx, need)) != SWG_OK) return rc;
     }
@@ -634,6 +564,17 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
             HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream2));
             HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[7], 0));
         }
+    } else if (bits == 32 && use_diag32) {
+        p.profile = ctx->d_profile[1];
+        p.queue = db->d_counters + 0;
+        p.list = nullptr;
+        p.list_count = nullptr;
+        p.n_items = (uint32_t)n_slots;
+        p.npass = (uint32_t)npass32;
+        p.go = go;
+        p.ge = ge;
+        p.scratch_wg_dwords = ((uint64_t)db->max_nblk * 4 + 4) * 4;
+        HIP_TRY(ctx, swg_launch_diag32(16, (int)std::min<size_t>((size_t)ctx->n_cu, (n_slots + 15) / 16), p, s));
     } else {
         p.profile = ctx->d_profile[bits == 16 ? 0 : 1];
         p.queue = db->d_counters + 0;
@@ -661,11 +602,27 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         p.list = db->d_list;
         p.list_count = db->d_counters + 1;
         p.n_items = 0;
-        p.npass = (uint32_t)re_pl.npass;
         p.go = go;
         p.ge = ge;
-        p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * re_pl.info.nb;
-        HIP_TRY(ctx, swg_launch_fill(32, re_pl.variant, re_pl.W, re_pl.workgroups, p, s));
+        if (use_diag32) {
+            // how many were flagged decides the shape of the re-score (4 bytes over PCIe):
+            // usually none, then nothing is launched; a few long ones get a whole CU each
+            uint32_t n_sat = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&n_sat, db->d_counters + 1, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            if (n_sat > 0) {
+                int W = (int)((n_sat + (uint32_t)ctx->n_cu - 1) / (uint32_t)ctx->n_cu);
+                W = std::min(16, std::max(4, (W + 3) / 4 * 4));
+                const int wgs = (int)std::min<uint32_t>((uint32_t)ctx->n_cu, (n_sat + W - 1) / W);
+                p.npass = (uint32_t)npass32;
+                p.scratch_wg_dwords = ((uint64_t)db->max_nblk * 4 + 4) * 4;
+                HIP_TRY(ctx, swg_launch_diag32(W, wgs, p, s));
+            }
+        } else {
+            p.npass = (uint32_t)re_pl.npass;
+            p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * re_pl.info.nb;
+            HIP_TRY(ctx, swg_launch_fill(32, re_pl.variant, re_pl.W, re_pl.workgroups, p, s));
+        }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
 
@@ -732,6 +689,14 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
             st.long_streams = (int32_t)db->diag[1].n_streams;
             st.cells_padded += 2ull * lp.npass * lp.G * lp.K * db->diag[1].total_blocks * 4ull;
         }
+    } else if (bits == 32 && use_diag32) {
+        st.engine = 2;
+        st.cols_per_wave = SWG_DIAG32_K;
+        st.group_lanes = 64;
+        st.waves = 16;
+        st.passes = npass32;
+        st.workgroups = (int)std::min<size_t>((size_t)ctx->n_cu, (n_slots + 15) / 16);
+        st.cells_padded = (uint64_t)npass32 * 64 * SWG_DIAG32_K * ((uint64_t)db->rows_padded);
     } else {
         st.engine = 1;
         st.cols_per_wave = main_pl.K;

@@ -37,16 +37,55 @@ uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)
     return lo;
 }
 
-bool swg_plan_diag(size_t lq, uint64_t n_pairs, uint64_t pair_rows_total, uint64_t longest_rows, int n_cu,
-                   long opt_cols, long opt_group, long opt_waves, SwgDiagPlan *out)
+// Cost model (cycles of one SIMD per packed/DPP wave-instruction, measured):
+//   a lane group spends (10*K + overhead) instructions per database row; a SIMD shared by
+//   `wps` waves issues one such instruction every kCyclesPerInstr[wps] cycles, so one wave
+//   advances a row every instr * kCyclesPerInstr[wps] * wps cycles.  A search lasts as long
+//   as the larger of (a) all work divided by all SIMDs and (b) the longest chain of rows any
+//   one lane group has to walk.  The few longest pairs can be split off into their own class
+//   (64 lanes per pair, fewest columns per lane, raised wave priority) so that (b) does not
+//   dominate small databases.
+static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 18.0 : 14.0); }
+
+static bool long_class_geometry(size_t lq, SwgDiagPlan *lp)
 {
-    const int nv = swg_num_diag_variants();
+    bool ok = false;
+    double best = 1e300;
+    for (int v = 0; v < swg_num_diag_variants(); ++v) {
+        const SwgKernelInfo info = swg_diag_variant_info(v);
+        const size_t cols = 64u * (size_t)info.K;
+        if (cols * 64 > 160 * 1024) continue;
+        const int npass = (int)((lq + cols - 1) / cols);
+        const double cost = npass * instr_per_row(info.K, 64);
+        if (cost < best) {
+            best = cost;
+            lp->variant = v;
+            lp->K = info.K;
+            lp->G = 64;
+            lp->npass = npass;
+            lp->W = 4;
+            lp->lds_bytes = cols * 64;
+            ok = true;
+        }
+    }
+    return ok;
+}
+
+int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
+                       long opt_long_split, bool allow_split, SwgDiagWork *wk)
+{
+    const uint64_t n_pairs = swg_db_pair_count(db);
+    if (n_pairs == 0) return 0;
+    uint64_t longest = 0;
+    const uint64_t rows_all = swg_db_pair_rows(db, 0, n_pairs, &longest);
+    SwgDiagPlan lp;
+    memset(&lp, 0, sizeof lp);
+    const bool have_long = allow_split && opt_long_split >= 0 && long_class_geometry(lq, &lp);
+    const double simds = 4.0 * n_cu;
     const int groups[3] = {16, 32, 64};
-    bool found = false;
-    SwgDiagPlan best;
-    memset(&best, 0, sizeof best);
-    best.est_ms = 1e300;
-    for (int v = 0; v < nv; ++v) {
+    double best_ms = 1e300;
+    wk->n_classes = 0;
+    for (int v = 0; v < swg_num_diag_variants(); ++v) {
         const SwgKernelInfo info = swg_diag_variant_info(v);
         if (opt_cols > 0 && info.K != (int)opt_cols) continue;
         for (int gi = 0; gi < 3; ++gi) {
@@ -57,42 +96,81 @@ bool swg_plan_diag(size_t lq, uint64_t n_pairs, uint64_t pair_rows_total, uint64
             if (lds > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
             const int NG = 64 / G;
-            const double instr = 11.0 * info.K + (G == 32 ? 18.0 : 14.0); // per lane per step
+            const double instr = instr_per_row(info.K, G);
             for (int wps = 1; wps <= 4; ++wps) {
                 const int W = 4 * wps;
                 if (W > info.max_waves) continue;
                 if (opt_waves > 0 && W != (int)opt_waves) continue;
-                // workgroups resident per CU: wave budget and LDS
-                int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)));
-                // several workgroups per CU raise the waves per SIMD
+                const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)));
                 const int eff_wps = std::min(4, wps * per_cu);
-                const uint64_t hw_streams = (uint64_t)n_cu * per_cu * W * NG;
-                const uint64_t spw = (uint64_t)W * NG; // lane groups of one workgroup
-                uint64_t n_streams = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, n_pairs));
-                n_streams = (n_streams + spw - 1) / spw * spw;
                 const double cps = kCyclesPerInstr[eff_wps];
-                // balanced share: rows per stream * steps; each wave-step serves NG streams
-                const double rows_per_stream = (double)pair_rows_total / (double)n_streams;
-                const double crit_rows = std::max<double>(rows_per_stream, (double)longest_rows) + G;
-                const double cycles = crit_rows * npass * instr * cps * eff_wps;
-                const double ms = cycles / 2.35e9 * 1e3;
-                if (ms < best.est_ms) {
-                    best.variant = v;
-                    best.K = info.K;
-                    best.G = G;
-                    best.npass = npass;
-                    best.W = W;
-                    best.n_streams = (uint32_t)n_streams;
-                    best.workgroups = (int)((n_streams + (uint64_t)W * NG - 1) / ((uint64_t)W * NG));
-                    best.lds_bytes = lds;
-                    best.est_ms = ms;
-                    found = true;
+                const uint64_t spw = (uint64_t)W * NG;
+                const uint64_t hw_streams = (uint64_t)n_cu * per_cu * spw;
+                for (int split = 0; split <= (have_long ? 1 : 0); ++split) {
+                    uint64_t n_long = 0, rows_long = 0, longest_bulk = longest, longest_long = 0;
+                    uint64_t streams0 = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, n_pairs));
+                    streams0 = (streams0 + spw - 1) / spw * spw;
+                    if (split) {
+                        uint64_t thr = opt_long_split > 0 ? (uint64_t)opt_long_split
+                                                          : (uint64_t)(0.33 * (double)rows_all / (double)streams0);
+                        thr = std::max<uint64_t>(thr, 64);
+                        if (longest <= thr) continue;
+                        n_long = swg_db_pairs_longer_than(db, thr);
+                        if (n_long == 0 || n_long * 4 > n_pairs) continue;
+                        rows_long = swg_db_pair_rows(db, 0, n_long, &longest_long);
+                        longest_bulk = 2ull + db->lens[2 * n_long];
+                    }
+                    const uint64_t n_bulk = n_pairs - n_long;
+                    const uint64_t rows_bulk = rows_all - rows_long;
+                    uint64_t streams = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, n_bulk));
+                    streams = (streams + spw - 1) / spw * spw;
+                    // (a) throughput: SIMD-cycles of both classes over all SIMDs
+                    double work = (double)rows_bulk / NG * npass * instr * cps;
+                    double crit = (std::max<double>((double)rows_bulk / streams, (double)longest_bulk) + G) * npass *
+                                  instr * cps * eff_wps;
+                    uint64_t lstreams = 0;
+                    if (split) {
+                        lstreams = std::max<uint64_t>(1, std::min<uint64_t>((n_long + 1) / 2, (uint64_t)n_cu * 4));
+                        lstreams = (lstreams + 3) / 4 * 4;
+                        const double linstr = instr_per_row(lp.K, 64);
+                        work += (double)rows_long * lp.npass * linstr * cps;
+                        const double lcrit = (std::max<double>((double)rows_long / lstreams, (double)longest_long) + 64) *
+                                             lp.npass * linstr * 7.5; // raised priority: close to a wave alone
+                        crit = std::max(crit, lcrit);
+                    }
+                    double cycles = std::max(work / simds, crit);
+                    if (npass > 1) cycles *= 1.12; // profile reloads, pass barriers, edge spills
+                    const double ms = cycles / 2.35e9 * 1e3;
+                    if (ms < best_ms) {
+                        best_ms = ms;
+                        SwgDiagPlan &b = wk->plan[0];
+                        b.variant = v;
+                        b.K = info.K;
+                        b.G = G;
+                        b.npass = npass;
+                        b.W = W;
+                        b.n_streams = (uint32_t)streams;
+                        b.workgroups = (int)(streams / spw);
+                        b.lds_bytes = lds;
+                        b.est_ms = ms;
+                        wk->pair_begin[0] = n_long;
+                        wk->pair_end[0] = n_pairs;
+                        wk->n_classes = 1;
+                        if (split) {
+                            wk->n_classes = 2;
+                            wk->plan[1] = lp;
+                            wk->plan[1].n_streams = (uint32_t)lstreams;
+                            wk->plan[1].workgroups = (int)(lstreams / 4);
+                            wk->plan[1].est_ms = ms;
+                            wk->pair_begin[1] = 0;
+                            wk->pair_end[1] = n_long;
+                        }
+                    }
                 }
             }
         }
     }
-    if (found) *out = best;
-    return found;
+    return wk->n_classes;
 }
 
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,

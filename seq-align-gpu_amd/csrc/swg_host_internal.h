@@ -97,9 +97,19 @@ struct SwgDiagPlan {
     size_t lds_bytes;
     double est_ms;
 };
-// geometry for one query length on one device; returns false if the diagonal engine cannot run it
-bool swg_plan_diag(size_t lq, uint64_t n_pairs, uint64_t pair_rows_total, uint64_t longest_rows, int n_cu,
-                   long opt_cols, long opt_group, long opt_waves, SwgDiagPlan *out);
+// The diagonal engine's work split: class 0 = the bulk of the pairs, class 1 = the few
+// longest ones, which would otherwise be the serial tail of the whole search.  The long
+// class runs beside the bulk on a second HIP stream with 64 lanes per pair and as few
+// columns per lane as cover the query, i.e. with the shortest possible chain per row.
+struct SwgDiagWork {
+    int n_classes = 0;
+    SwgDiagPlan plan[2];
+    uint64_t pair_begin[2] = {0, 0}, pair_end[2] = {0, 0};
+};
+// geometry of both classes for one query length on one device; returns the number of
+// classes (0: the diagonal engine cannot run this with the given options)
+int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
+                       long opt_long_split, bool allow_split, SwgDiagWork *wk);
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
                            uint32_t streams_per_wg, SwgDiagLayout *out);
 uint64_t swg_db_pair_count(const swg_db *db);

@@ -66,6 +66,12 @@ SwgKernelInfo swg_variant_info(int bits, int variant);
 hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups,
                            const SwgFillParams &p, hipStream_t stream);
 
+// int32 diagonal engine: 64 lanes x SWG_DIAG32_K columns per pass, one sequence per wavefront.
+// Uses SwgFillParams: list/list_count/n_items = sequences (sorted ranks) to score, queue = work
+// counter, profile = int32 [npass][16*K][32][4], scratch_wg_dwords = dwords per WAVEFRONT.
+#define SWG_DIAG32_K 16
+hipError_t swg_launch_diag32(int W, int workgroups, const SwgFillParams &p, hipStream_t stream);
+
 int swg_num_diag_variants();
 SwgKernelInfo swg_diag_variant_info(int variant); // K, max_waves (wave budget of one CU)
 hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, size_t lds_bytes,

@@ -624,6 +624,162 @@ __global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, 
 }
 
 // ---------------------------------------------------------------------------
+// The int32 diagonal fill: 64 lanes share ONE sequence, exact recurrence
+// ---------------------------------------------------------------------------
+// Used for the sequences the int16 fill flagged as saturated (typically a handful
+// of very long, very similar ones: exactly the shape that needs the shortest chain
+// per row), for gap scores the packed form cannot express, and when forced.  A
+// workgroup takes W consecutive entries of the work list, one per wavefront; all
+// of them walk the query pass by pass (the int32 profile slice of a pass is shared
+// in LDS), lane g holding K columns, the leader lane turning the bins' residue
+// dwords into tokens on the fly.
+template <int K> struct CellsDiag32 {
+    static constexpr int CHUNK = 512; // 32 residues x 4 columns x int32
+    int U[K], A[K], D[K];
+    int best, ddl;
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) U[k] = A[k] = D[k] = 0;
+        best = 0;
+        ddl = 0;
+    }
+
+    DEVINL void row(const uint8_t *prof, uint32_t off, int el, int eb, int ed, int go, int ge, int &ol,
+                    int &ob, int &od)
+    {
+        int dd = ddl;
+        int ll = el, bl = eb;
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) {
+            const int4 sv = *reinterpret_cast<const int4 *>(prof + off + c * CHUNK);
+            const int s[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * c + u;
+                const int h = imax(dd + s[u], 0);             // src/alignment.c:124-129
+                const int a = imax3(U[k] + go, A[k] + ge, 0); // src/alignment.c:142-147
+                const int b = imax3(ll + go, bl + ge, 0);     // src/alignment.c:156-161
+                dd = D[k];
+                U[k] = imax(h, b);
+                ll = imax(h, a);
+                D[k] = imax(ll, b);
+                A[k] = a;
+                bl = b;
+                best = imax(best, h);                         // src/alignment.c:133
+            }
+        }
+        ddl = ed;
+        ol = ll;
+        ob = bl;
+        od = D[K - 1];
+    }
+};
+
+DEVINL int dpp_wave_shr1(int keep, int src)
+{
+    return __builtin_amdgcn_update_dpp(keep, src, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+#define SWG_PAD32 (-(1 << 29))
+
+template <int K, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void swg_diag32_kernel(const SwgFillParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // int32 profile slice + 2 words
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const bool leader = lane == 0, tail = lane == 63;
+    const uint32_t slice = 64u * K * 128u; // bytes of one pass: 64*K columns x 32 residues x 4 B
+    uint32_t *wgword = reinterpret_cast<uint32_t *>(smem + slice);
+    const uint32_t n_items = p.list_count ? *p.list_count : p.n_items; // sequences to score
+    const uint32_t base = (uint32_t)lane * (K / 4) * 512u;
+    const int npass = (int)p.npass;
+    uint4 *sp = reinterpret_cast<uint4 *>(p.scratch) +
+                ((size_t)blockIdx.x * W + w) * (p.scratch_wg_dwords / 4); // rows of this wavefront
+
+    for (;;) {
+        // ---- next batch of W sequences for this workgroup ----------------------
+        __syncthreads();
+        if (threadIdx.x == 0) wgword[0] = atomicAdd(p.queue, 1u);
+        __syncthreads();
+        const uint32_t batch = wgword[0];
+        if ((uint64_t)batch * W >= n_items) break;
+        const uint32_t idx = batch * W + w;
+        const bool valid = idx < n_items;
+        uint32_t rank = 0, nblk = 0;
+        const uint32_t *rp = p.residues;
+        if (valid) {
+            rank = p.list ? p.list[idx] : idx;
+            const uint32_t b = rank / SWG_BIN;
+            nblk = rank < p.n_bins * SWG_BIN ? p.bin_nblk[b] : 0u;
+            rp = p.residues + (nblk ? p.bin_off[b] : 0) + SWG_BIN_COLUMN(rank % SWG_BIN);
+        }
+        nblk = __builtin_amdgcn_readfirstlane(nblk);
+        const uint32_t rows = nblk * 4u;
+        // stream of this wavefront: block 0 = (pad, pad, pad, reset), blocks 1..nblk = residues
+        const uint32_t nsteps = nblk ? (nblk + 1u) * 4u + 64u : 0u;
+
+        for (int pass = 0; pass < npass; ++pass) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            {
+                const uint8_t *src = p.profile + (size_t)pass * slice;
+                for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
+                    *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(src + o);
+            }
+            __syncthreads();
+
+            CellsDiag32<K> cells;
+            cells.reset();
+            int tok = 0, o_l = 0, o_b = 0, o_d = 0, c_out = 0;
+            uint32_t cur = 0u, nxt = (leader && nblk > 0u) ? rp[0] : 0u;
+            for (uint32_t s4 = 0; s4 < nsteps; s4 += 4u) {
+                const uint32_t blk = s4 / 4u; // block 0 is the reset block
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int fresh;
+                    if (blk == 0u)
+                        fresh = r == 3 ? (int)SWG_TOK_RESET : 0;
+                    else
+                        fresh = (int)((cur >> (8 * r)) & 0xF8u) | ((blk == nblk && r == 3) ? (int)SWG_TOK_LAST : 0);
+                    // edge of the column left of the query: zero, or what the tail lane
+                    // spilled for this row in the previous pass
+                    int lm = 0, lb = 0, ld = 0;
+                    const uint32_t lrow = s4 + (uint32_t)r; // stream row handled by the leader now
+                    if (pass > 0 && leader && lrow < rows + 4u) {
+                        const uint4 v = load_edge_l2(sp + lrow);
+                        lm = (int)v.x;
+                        lb = (int)v.y;
+                        ld = (int)v.z;
+                    }
+                    tok = dpp_wave_shr1(fresh, tok);
+                    const int el = dpp_wave_shr1(lm, o_l);
+                    const int eb = dpp_wave_shr1(lb, o_b);
+                    const int ed = dpp_wave_shr1(ld, o_d);
+                    const int cin = dpp_wave_shr1(0, c_out);
+                    const bool rst = (tok & (int)SWG_TOK_RESET) != 0;
+                    if (rst) cells.best = 0;
+                    cells.row(smem, base + (((uint32_t)tok & 0xF8u) << 1), el, eb, ed, rst ? SWG_PAD32 : p.go,
+                              rst ? SWG_PAD32 : p.ge, o_l, o_b, o_d);
+                    c_out = imax(cin, cells.best);
+                    if (tail) {
+                        if ((tok & (int)SWG_TOK_LAST) && valid) atomicMax(p.scores + rank, c_out);
+                        const uint32_t trow = lrow - 63u; // stream row handled by the tail lane now
+                        if (pass + 1 < npass && trow < rows + 4u)
+                            sp[trow] = make_uint4((uint32_t)o_l, (uint32_t)o_b, (uint32_t)o_d, 0u);
+                    }
+                }
+                cur = nxt;
+                nxt = (leader && blk + 1u < nblk) ? rp[(size_t)(blk + 1u) * SWG_BIN] : 0u;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // device top-K: histogram -> threshold -> compaction of the few candidates
 // ---------------------------------------------------------------------------
 // Hits are ordered by (score desc, original index asc) = descending 64-bit key.
@@ -820,6 +976,19 @@ hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t swg_launch_diag32(int W, int workgroups, const SwgFillParams &p, hipStream_t stream)
+{
+    constexpr int K = SWG_DIAG32_K, MAXW = 16;
+    if (W < 1 || W > MAXW || workgroups < 1) return hipErrorInvalidValue;
+    const size_t lds = 64u * K * 128u + 16;
+    auto k = swg_diag32_kernel<K, MAXW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -33,10 +33,7 @@ def test_golden_through_search(swg, ctx, name, engine):
     g = load_golden(name)
     _setup(ctx, g)
     gaps_ok = g["gaps"][0] <= 0 and g["gaps"][1] <= 0
-    if gaps_ok:
-        ctx.set_option("engine", engine)     # 1 systolic, 2 diagonal (int16 path only)
-    elif engine == 2:
-        pytest.skip("int32 path has one engine")
+    ctx.set_option("engine", engine)         # 1 systolic, 2 diagonal (both arithmetic widths)
     db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
     scores, hits, st = ctx.search(db, k=10)
     assert np.array_equal(scores, _truth(g)), (name, st)
@@ -45,17 +42,18 @@ def test_golden_through_search(swg, ctx, name, engine):
     best = sorted(((-int(s), i) for i, s in enumerate(_truth(g))))[:10]
     assert hits == [(-s, i) for s, i in best]
     assert st["path_bits"] == (16 if gaps_ok else 32)
-    if gaps_ok:
-        assert st["engine"] == engine
+    assert st["engine"] == engine
     assert st["cells"] == len(g["query"]) * len(g["flat"])
     db.close()
 
 
+@pytest.mark.parametrize("engine", [1, 2])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_forced_int32(swg, ctx, name):
+def test_golden_forced_int32(swg, ctx, name, engine):
     g = load_golden(name)
     _setup(ctx, g)
     ctx.set_option("force_bits", 32)
+    ctx.set_option("engine", engine)
     db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
     scores, _, st = ctx.search(db)
     assert st["path_bits"] == 32
@@ -132,6 +130,7 @@ def test_multipass_int32_and_few_workgroups(swg, ctx):
     g = load_golden("blosum62_lq3000")
     _setup(ctx, g)
     ctx.set_option("force_bits", 32)
+    ctx.set_option("engine", 1)
     ctx.set_option("max_waves", 3)
     ctx.set_option("workgroups", 1)
     db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
