@@ -10,7 +10,7 @@
 
 // Measured on MI355X (profiles/r01_valu_issue_rates.txt): cycles one SIMD needs per
 // packed-int16 / DPP / v_perm wave-instruction when `wps` waves share it.
-static const double kCyclesPerInstr[5] = {0.0, 6.8, 5.1, 4.8, 4.56};
+static const double kCyclesPerInstr[5] = {0.0, 6.8, 5.3, 5.05, 4.56};
 
 uint64_t swg_db_pair_count(const swg_db *db) { return (db->n_local + 1) / 2; }
 
@@ -139,7 +139,7 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
                         crit = std::max(crit, lcrit);
                     }
                     double cycles = std::max(work / simds, crit);
-                    if (npass > 1) cycles *= 1.12; // profile reloads, pass barriers, edge spills
+                    cycles *= 1.0 + 0.04 * (npass - 1); // profile reloads, pass barriers, edge spills
                     const double ms = cycles / 2.35e9 * 1e3;
                     if (ms < best_ms) {
                         best_ms = ms;
