@@ -103,17 +103,12 @@ def main():
     residues = int(db.residues)
 
     K = args.topk
-    keybuf = torch.zeros(world * K, dtype=torch.int64, device="cuda") if world > 1 else None
+    merger = TopKMerger(swg, K, rank, world, "cuda") if world > 1 else None
 
     def step():
         _, hits, st = ctx.search(db, want_scores=False, k=K)
         if world > 1:
-            # global top-K: each rank fills its own K-slot segment, one max-all-reduce over xGMI
-            mine = torch.tensor([swg.hit_key(s, i) for s, i in hits] + [0] * (K - len(hits)), dtype=torch.int64)
-            keybuf.zero_()
-            keybuf[rank * K:(rank + 1) * K] = mine.cuda()
-            dist.all_reduce(keybuf, op=dist.ReduceOp.MAX)
-            hits = swg.topk_merge_keys(keybuf.cpu().numpy().astype(np.uint64), K)
+            hits = merger.merge(hits)
         return hits, st
 
     for _ in range(args.warmup):
@@ -201,6 +196,28 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+class TopKMerger:
+    """Global top-K over the ranks' shards: every rank writes the 64-bit keys of its own K hits
+    (score << 32 | ~index: larger = better, total order) into its K-slot segment of a zeroed
+    n*K buffer; ONE max-all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests) leaves the
+    union on every rank, which then keeps the best K.  n*K*8 bytes: latency-bound."""
+
+    def __init__(self, swg, k, rank, world, device):
+        import torch
+        self.swg, self.k, self.rank, self.world = swg, k, rank, world
+        self.buf = torch.zeros(world * k, dtype=torch.int64, device=device)
+
+    def merge(self, hits):
+        import torch
+        import torch.distributed as dist
+        k = self.k
+        mine = torch.tensor([self.swg.hit_key(s, i) for s, i in hits] + [0] * (k - len(hits)), dtype=torch.int64)
+        self.buf.zero_()
+        self.buf[self.rank * k:(self.rank + 1) * k] = mine.to(self.buf.device)
+        dist.all_reduce(self.buf, op=dist.ReduceOp.MAX)
+        return self.swg.topk_merge_keys(self.buf.cpu().numpy().astype(np.uint64), k)
 
 
 def cpu_baseline(swg, q, flat, off, sc, lq):

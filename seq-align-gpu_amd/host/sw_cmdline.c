@@ -1,0 +1,224 @@
+/*
+ * sw_cmdline.c -- the `smith_waterman` tool over libswg (plain C host code).
+ *
+ * Same command line, same stdout as the reference's tool (flags:
+ * reference src/alignment_cmdline.c:205-292, output: src/tools/sw_cmdline.c:38-75
+ * and src/alignment_cmdline.c:274,529-530), with the whole timed
+ * fill region (src/alignment_cmdline.c:503-509) replaced by one swg_search()
+ * on the GPU.  Deliberate differences, all from SURVEY A.7:
+ *   - the database need not be length-sorted nor a multiple of 16 records;
+ *   - "Entry #n" is always the true 0-based record index (A.7-3);
+ *   - the substitution matrix is mandatory and undefined pairs score 0 (A.7-1,2);
+ *   - scores above 32767 are exact instead of wrapped (A.4);
+ *   - --topk K appends a ranked report; --gpu N selects the device.
+ * There is no CPU backend: without a GPU the tool fails with a message.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "../../include/swg.h"
+#include "../../include/swg_host.h"
+
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+static void usage(const char *argv0, const char *err)
+{
+    if (err) fprintf(stderr, "Error: %s\n", err);
+    fprintf(stderr,
+            "usage: %s [OPTIONS] --substitution_matrix <file> --files <query> <database>\n"
+            "  Smith-Waterman optimal local alignment score of one query against every\n"
+            "  record of a database (FASTA/FASTQ/plain, gzip ok), on an AMD MI355X.\n\n"
+            "  OPTIONS:\n"
+            "    --files <f1> <f2>    query file (first record) and database file\n"
+            "    --substitution_matrix <file>  scoring matrix (see data/*.txt)\n"
+            "    --gapopen <score>    [default: -2]\n"
+            "    --gapextend <score>  [default: -1]   gap of length N costs open + N*extend\n"
+            "    --match <score> --mismatch <score>   accepted, unused with a matrix\n"
+            "    --printseq           print sequences\n"
+            "    --printfasta         print record names\n"
+            "    --printmatrices --pretty --colour --scoring <x>   accepted, no effect\n"
+            "    --topk <K>           append the K best hits (score, index, name)\n"
+            "    --gpu <N>            HIP device ordinal [default: 0]\n",
+            argv0);
+    exit(EXIT_FAILURE);
+}
+
+static int parse_int(const char *s, long lo, long hi, long *out)
+{
+    char *end = NULL;
+    const long v = strtol(s, &end, 10);
+    if (end == s || *end != '\0' || v < lo || v > hi) return 0;
+    *out = v;
+    return 1;
+}
+
+static void die_illegal(char c)
+{
+    /* reference src/alignment_scoring.c:78-79 */
+    printf("Error: %c is not a legal character for the substitution matrix!\n", c);
+    exit(1);
+}
+
+int main(int argc, char **argv)
+{
+    swg_scoring sc;
+    swg_scoring_init(&sc);
+    const char *qpath = NULL, *dbpath = NULL;
+    int print_seq = 0, print_fasta = 0, have_matrix = 0;
+    long topk = 0, gpu = 0, v;
+    if (argc == 1) usage(argv[0], NULL);
+    for (int i = 1; i < argc; i++)
+        if (!strcasecmp(argv[i], "--help") || !strcasecmp(argv[i], "-help") || !strcasecmp(argv[i], "-h"))
+            usage(argv[0], NULL);
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (!strcasecmp(a, "--printseq")) print_seq = 1;
+        else if (!strcasecmp(a, "--printfasta")) print_fasta = 1;
+        else if (!strcasecmp(a, "--printmatrices") || !strcasecmp(a, "--pretty") || !strcasecmp(a, "--colour")) {
+        } else if (i == argc - 1) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "Unknown argument without parameter: %s", a);
+            usage(argv[0], msg);
+        } else if (!strcasecmp(a, "--scoring")) {
+            i++;
+        } else if (!strcasecmp(a, "--substitution_matrix")) {
+            char err[512];
+            if (swg_scoring_load_matrix(&sc, argv[i + 1], err, sizeof err) != SWG_OK) {
+                fprintf(stderr, "Error: %s\n", err);
+                return EXIT_FAILURE;
+            }
+            have_matrix = 1;
+            i++;
+        } else if (!strcasecmp(a, "--match") || !strcasecmp(a, "--mismatch")) {
+            if (!parse_int(argv[i + 1], INT_MIN, INT_MAX, &v)) usage(argv[0], "Invalid --match/--mismatch argument, must be an int");
+            if (!strcasecmp(a, "--match")) sc.match = (int)v; else sc.mismatch = (int)v;
+            i++;
+        } else if (!strcasecmp(a, "--gapopen") || !strcasecmp(a, "--gapextend")) {
+            /* the reference's score_t is int16 (src/alignment_cmdline.c:255-267) */
+            if (!parse_int(argv[i + 1], SHRT_MIN, SHRT_MAX, &v)) usage(argv[0], "Invalid --gapopen/--gapextend argument, must be an int");
+            if (!strcasecmp(a, "--gapopen")) sc.gap_open = (int)v; else sc.gap_extend = (int)v;
+            i++;
+        } else if (!strcasecmp(a, "--topk")) {
+            if (!parse_int(argv[i + 1], 0, 1 << 20, &topk)) usage(argv[0], "Invalid --topk argument");
+            i++;
+        } else if (!strcasecmp(a, "--gpu")) {
+            if (!parse_int(argv[i + 1], 0, 1023, &gpu)) usage(argv[0], "Invalid --gpu argument");
+            i++;
+        } else if (!strcasecmp(a, "--files")) {
+            if (i >= argc - 2) usage(argv[0], "--files option takes 2 arguments");
+            /* reference src/alignment_cmdline.c:274 */
+            printf("Query File=%s and Database File=%s\n", argv[i + 1], argv[i + 2]);
+            qpath = argv[i + 1];
+            dbpath = argv[i + 2];
+            i += 2;
+        } else {
+            char msg[256];
+            snprintf(msg, sizeof msg, "Unknown argument '%s'", a);
+            usage(argv[0], msg);
+        }
+    }
+    if (!qpath || !dbpath) usage(argv[0], "Both query and database files must be provided");
+    if (!have_matrix) usage(argv[0], "--substitution_matrix is required (the fill scores from the matrix only)");
+
+    char err[512];
+    swg_seqs q, db;
+    if (swg_seqs_read(qpath, 1, &q, err, sizeof err) != SWG_OK) {
+        fprintf(stderr, "Error: couldn't open query file %s\n", qpath);
+        return EXIT_SUCCESS; /* the reference returns from the driver and exits 0 */
+    }
+    if (q.n == 0 || q.seq_off[1] == 0) {
+        fprintf(stderr, "Error: Query file %s is empty or invalid\n", qpath);
+        return EXIT_SUCCESS;
+    }
+    if (swg_seqs_read(dbpath, 0, &db, err, sizeof err) != SWG_OK) {
+        fprintf(stderr, "Error: couldn't open database file %s\n", dbpath);
+        return EXIT_SUCCESS;
+    }
+    const size_t lq = (size_t)q.seq_off[1];
+    int8_t *qidx = (int8_t *)malloc(lq);
+    int8_t *didx = (int8_t *)malloc(db.n ? (size_t)db.seq_off[db.n] + 1 : 1);
+    if (!qidx || !didx) {
+        fprintf(stderr, "Error: out of memory\n");
+        return EXIT_FAILURE;
+    }
+    char bad = 0;
+    {
+        swg_seqs q1 = q;
+        q1.n = 1;
+        if (swg_seqs_to_indices(&q1, qidx, &bad) != SWG_OK) die_illegal(bad);
+    }
+    swg_query_sanitize(&sc, qidx, lq); /* reference src/alignment_cmdline.c:391-396 */
+    if (swg_seqs_to_indices(&db, didx, &bad) != SWG_OK) die_illegal(bad);
+
+    swg_ctx *ctx = NULL;
+    swg_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = (int)gpu;
+    if (swg_create(&cfg, &ctx) != SWG_OK) {
+        fprintf(stderr, "Error: %s\n", swg_global_error());
+        return EXIT_FAILURE;
+    }
+    swg_db *pdb = NULL;
+    int32_t *scores = (int32_t *)calloc(db.n ? db.n : 1, sizeof(int32_t));
+    swg_hit *hits = (swg_hit *)calloc(topk ? (size_t)topk : 1, sizeof(swg_hit));
+    size_t n_hits = 0;
+    swg_stats st;
+    memset(&st, 0, sizeof st);
+    int rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
+    if (rc == SWG_OK) rc = swg_set_query(ctx, qidx, lq);
+    if (rc == SWG_OK) {
+        rc = swg_db_pack(didx, db.seq_off, db.n, 0, 1, &pdb);
+        if (rc != SWG_OK) fprintf(stderr, "Error: %s\n", swg_global_error());
+    }
+    if (rc == SWG_OK) rc = swg_db_upload(ctx, pdb);
+    if (rc == SWG_OK) rc = swg_search(ctx, pdb, scores, hits, (size_t)topk, &n_hits, &st);
+    if (rc != SWG_OK) {
+        fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
+        return EXIT_FAILURE;
+    }
+
+    /* reference src/tools/sw_cmdline.c:38-75: per 16 records the query lines, then per record */
+    const char *qname = q.names + q.name_off[0];
+    for (size_t i = 0; i < db.n; i++) {
+        if (i % 16 == 0) {
+            if (print_fasta) {
+                fputs(qname, stdout);
+                putc('\n', stdout);
+            }
+            if (print_seq) {
+                fwrite(q.seq, 1, lq, stdout);
+                putc('\n', stdout);
+            }
+        }
+        printf("Entry #%lu:\n", (unsigned long)i);
+        if (print_fasta) {
+            fputs(db.names + db.name_off[i], stdout);
+            putc('\n', stdout);
+        }
+        if (print_seq) {
+            fwrite(db.seq + db.seq_off[i], 1, (size_t)(db.seq_off[i + 1] - db.seq_off[i]), stdout);
+            putc('\n', stdout);
+        }
+        printf("score: %i\n\n", scores[i]);
+    }
+    /* reference src/alignment_cmdline.c:529-530; the time is the device time of the fill */
+    printf("Total Time: %f\n", st.total_ms * 1e-3);
+    printf("Total Entries: %lu\n", (unsigned long)db.n);
+    if (topk > 0) {
+        printf("Top %lu hits (score, entry, name):\n", (unsigned long)n_hits);
+        for (size_t i = 0; i < n_hits; i++)
+            printf("%d\t%u\t%s\n", hits[i].score, hits[i].index, db.names + db.name_off[hits[i].index]);
+    }
+    fflush(stdout);
+    swg_db_free(pdb);
+    swg_destroy(ctx);
+    swg_seqs_free(&q);
+    swg_seqs_free(&db);
+    free(qidx);
+    free(didx);
+    free(scores);
+    free(hits);
+    return EXIT_SUCCESS;
+}

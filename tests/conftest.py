@@ -18,9 +18,8 @@ def pytest_configure(config):
 
 
 def _ensure_built():
-    lib = os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so")
-    if not os.path.exists(lib):
-        swg_loader.build_module().build()
+    # incremental: a no-op when libswg.so, the CLI and the oracle are newer than their sources
+    swg_loader.build_module().build(verbose=False)
     orc = swg_loader.oracle()
     if not os.path.exists(orc.ORACLE_SO):
         orc.build()

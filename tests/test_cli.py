@@ -1,0 +1,111 @@
+"""The `smith_waterman` tool (plain-C host over libswg): flags and stdout of the reference tool
+(SURVEY A.6).  The CPU tests cover argument handling and the no-GPU failure; the GPU test is
+BASELINE config 1 -- a 128-aa query against a 1k-sequence synthetic database through the tool --
+checked entry by entry the way the reference's own test/tests.py does (regex over `Entry #n:` /
+`score:`), against the oracle."""
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CLI = os.path.join(ROOT, "seq-align-gpu_amd", "bin", "smith_waterman")
+B62 = os.path.join(ROOT, "seq-align-gpu_amd", "data", "BLOSUM62.txt")
+ENTRY_RX = re.compile(r"Entry\s+#(\d+):\s*score:\s*([+-]?\d+)", re.IGNORECASE)   # reference test/tests.py:52
+TIME_RX = re.compile(r"Total Time: ([0-9]*\.?[0-9]+)")                             # reference benchmarks/benchmark.py:29
+
+
+def _letters(swg, idx):
+    return "".join(chr(swg.lib.swg_index_letter(int(v))) for v in idx)
+
+
+def _write_fasta(path, names, seqs, width=60, gz=False):
+    op = gzip.open if gz else open
+    with op(path, "wt") as f:
+        for n, s in zip(names, seqs):
+            f.write(">%s\n" % n)
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + "\n")
+
+
+def _run(*args):
+    return subprocess.run([CLI] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_cli_argument_handling(swg, tmp_path):
+    assert os.path.exists(CLI)
+    r = _run()
+    assert r.returncode != 0 and "usage:" in r.stderr
+    r = _run("--bogus", "1")
+    assert r.returncode != 0 and "Unknown argument" in r.stderr
+    r = _run("--files", "a.fa")
+    assert r.returncode != 0
+    q = tmp_path / "q.fa"
+    q.write_text(">q\nACDE\n")
+    r = _run("--files", str(q), str(q))
+    assert r.returncode != 0 and "--substitution_matrix is required" in r.stderr
+    r = _run("--substitution_matrix", str(tmp_path / "none.txt"), "--files", str(q), str(q))
+    assert r.returncode != 0 and "substitution matrix" in r.stderr
+    r = _run("--substitution_matrix", B62, "--gapopen", "x", "--files", str(q), str(q))
+    assert r.returncode != 0 and "--gapopen" in r.stderr
+
+
+def test_cli_refuses_without_gpu(swg, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    q = tmp_path / "q.fa"
+    q.write_text(">q\nACDEFGHIKL\n")
+    r = _run("--substitution_matrix", B62, "--files", str(q), str(q))
+    assert r.returncode != 0 and "no CPU backend" in r.stderr
+    assert "Query File=%s and Database File=%s" % (q, q) in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_config1_against_oracle(swg, orc, tmp_path):
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(0x5EED0001, 128)
+    flat, off = swg.synth_db(0x5EED0001, 1024)
+    # the tool does not need a sorted database nor a multiple of 16 records: shuffle, drop a few
+    rng = np.random.default_rng(1)
+    keep = rng.permutation(1024)[:1003]
+    seqs = [_letters(swg, flat[int(off[i]):int(off[i + 1])]) for i in keep]
+    seqs[5] = seqs[5].lower()                                  # case folds (letters_to_index)
+    names = ["db%d some description" % i for i in range(len(seqs))]
+    qf, df = tmp_path / "query.fasta", tmp_path / "db.fasta.gz"
+    _write_fasta(qf, ["query1"], [_letters(swg, q)])
+    _write_fasta(df, names, seqs, gz=True)
+    want = [orc.pair(q, swg.letters_to_indices(s), sc.table(), -2, -1) for s in seqs]
+
+    r = _run("--substitution_matrix", B62, "--files", str(qf), str(df))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "Query File=%s and Database File=%s" % (qf, df)
+    got = {int(m.group(1)): int(m.group(2)) for m in ENTRY_RX.finditer(r.stdout)}
+    assert got == dict(enumerate(want))
+    assert lines[1:4] == ["Entry #0:", "score: %d" % want[0], ""]
+    assert TIME_RX.search(r.stdout) and lines[-1] == "Total Entries: %d" % len(seqs)
+    assert lines[-2].startswith("Total Time: ")
+
+    # non-default gap scores, names/sequences printed, top-K report
+    r = _run("--substitution_matrix", B62, "--gapopen", "-10", "--gapextend", "-1", "--printfasta", "--printseq",
+             "--topk", "5", "--files", str(qf), str(df))
+    assert r.returncode == 0, r.stderr
+    want2 = np.array([orc.pair(q, swg.letters_to_indices(s), sc.table(), -10, -1) for s in seqs])
+    lines = r.stdout.splitlines()
+    assert lines[1:8] == ["query1", _letters(swg, q), "Entry #0:", names[0], seqs[0], "score: %d" % want2[0], ""]
+    i16 = lines.index("Entry #16:")
+    assert lines[i16 - 2:i16] == ["query1", _letters(swg, q)]          # query lines once per 16 entries
+    top = lines[lines.index("Top 5 hits (score, entry, name):") + 1:][:5]
+    exp = orc.topk(want2.astype(np.int32), 5)
+    assert top == ["%d\t%d\t%s" % (s, i, names[i]) for s, i in exp]
+
+    # an illegal residue: the reference's message and exit status 1
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">x\nAC-DE\n")
+    r = _run("--substitution_matrix", B62, "--files", str(qf), str(bad))
+    assert r.returncode == 1 and "Error: - is not a legal character for the substitution matrix!" in r.stdout
