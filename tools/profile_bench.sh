@@ -1,0 +1,32 @@
+# rocprofv3 evidence for bench.py's default command (config 2, 1 GPU): kernel trace + stats,
+# then HBM counters in their own passes (MI355X_MICROARCH.md, HBM / rocprofv3 PMC sections).
+CFG=${1:-2}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_c$CFG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--config $CFG --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $R/bench.py $ARGS > $OUT/sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/lds -- python3 $R/bench.py $ARGS > $OUT/lds.log 2>&1
+python3 - <<PY
+import csv, glob, json, collections, os
+out = "$OUT"
+summary = {"config": $CFG, "command": "python bench.py $ARGS"}
+for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+    summary["kernel_stats"] = [r for r in csv.DictReader(open(f))]
+ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("fetch", "write", "sq", "lds"):
+    for f in glob.glob(out + "/%s/**/*counter_collection.csv" % d, recursive=True):
+        for r in csv.DictReader(open(f)):
+            ctr[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary["pmc_mean_per_launch"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in ctr.items()}
+json.dump(summary, open(out + "/summary.json", "w"), indent=1)
+for k, cs in summary["pmc_mean_per_launch"].items():
+    if "diag" in k or "fill" in k:
+        print(k, {c: "%.4g" % v for c, v in cs.items()})
+for r in summary.get("kernel_stats", [])[:6]:
+    print(r["Name"][:70], r["Calls"], r["AverageNs"], r["Percentage"])
+PY
