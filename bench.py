@@ -58,6 +58,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # SWG_BENCH_FORCE_DIST=1: take the collective path even with one rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("SWG_BENCH_FORCE_DIST") == "1"
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
@@ -66,14 +68,16 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     lib_path = os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so")
     if not os.path.exists(lib_path):
         if rank == 0:
             swg_loader.build_module().build()
-        if world > 1:
+        if use_dist:
             dist.barrier()
     swg = swg_loader.load()
 
@@ -103,11 +107,11 @@ def main():
     residues = int(db.residues)
 
     K = args.topk
-    merger = TopKMerger(swg, K, rank, world, "cuda") if world > 1 else None
+    merger = TopKMerger(swg, K, rank, world, "cuda") if use_dist else None
 
     def step():
         _, hits, st = ctx.search(db, want_scores=False, k=K)
-        if world > 1:
+        if use_dist:
             hits = merger.merge(hits)
         return hits, st
 
@@ -116,7 +120,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +136,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     cells_local = lq * residues
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -194,7 +198,7 @@ def main():
 
     db.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

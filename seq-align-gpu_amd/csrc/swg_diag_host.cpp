@@ -47,27 +47,45 @@ uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)
 //   dominate small databases.
 static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 18.0 : 14.0); }
 
-static bool long_class_geometry(size_t lq, SwgDiagPlan *lp)
+// Long class: the cheapest geometry (instructions per pair-row, column padding included)
+// whose longest chain still finishes within `budget_cycles`; if none does, the shortest chain.
+static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_cycles, SwgDiagPlan *lp)
 {
-    bool ok = false;
-    double best = 1e300;
+    bool ok = false, ok_fit = false;
+    double best_cost = 1e300, best_depth = 1e300;
+    SwgDiagPlan fit, fast;
+    const int groups[2] = {32, 64};
     for (int v = 0; v < swg_num_diag_variants(); ++v) {
         const SwgKernelInfo info = swg_diag_variant_info(v);
-        const size_t cols = 64u * (size_t)info.K;
-        if (cols * 64 > 160 * 1024) continue;
-        const int npass = (int)((lq + cols - 1) / cols);
-        const double cost = npass * instr_per_row(info.K, 64);
-        if (cost < best) {
-            best = cost;
-            lp->variant = v;
-            lp->K = info.K;
-            lp->G = 64;
-            lp->npass = npass;
-            lp->W = 4;
-            lp->lds_bytes = cols * 64;
-            ok = true;
+        for (int gi = 0; gi < 2; ++gi) {
+            const int G = groups[gi];
+            const size_t cols = (size_t)G * info.K;
+            if (cols * 64 > 160 * 1024) continue;
+            const int npass = (int)((lq + cols - 1) / cols);
+            const double instr = npass * instr_per_row(info.K, G);
+            const double cost = instr / (64 / G);                     // per pair-row
+            const double depth = ((double)longest_rows + G) * instr * 7.5; // raised priority: ~a wave alone
+            SwgDiagPlan c;
+            memset(&c, 0, sizeof c);
+            c.variant = v;
+            c.K = info.K;
+            c.G = G;
+            c.npass = npass;
+            c.W = 4;
+            c.lds_bytes = cols * 64;
+            if (depth <= budget_cycles && cost < best_cost) {
+                best_cost = cost;
+                fit = c;
+                ok_fit = true;
+            }
+            if (depth < best_depth) {
+                best_depth = depth;
+                fast = c;
+                ok = true;
+            }
         }
     }
+    if (ok_fit) *lp = fit; else if (ok) *lp = fast;
     return ok;
 }
 
@@ -78,9 +96,7 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
     if (n_pairs == 0) return 0;
     uint64_t longest = 0;
     const uint64_t rows_all = swg_db_pair_rows(db, 0, n_pairs, &longest);
-    SwgDiagPlan lp;
-    memset(&lp, 0, sizeof lp);
-    const bool have_long = allow_split && opt_long_split >= 0 && long_class_geometry(lq, &lp);
+    const bool have_long = allow_split && opt_long_split >= 0;
     const double simds = 4.0 * n_cu;
     const int groups[3] = {16, 32, 64};
     double best_ms = 1e300;
@@ -129,13 +145,19 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
                     double crit = (std::max<double>((double)rows_bulk / streams, (double)longest_bulk) + G) * npass *
                                   instr * cps * eff_wps;
                     uint64_t lstreams = 0;
+                    SwgDiagPlan lp;
+                    memset(&lp, 0, sizeof lp);
                     if (split) {
-                        lstreams = std::max<uint64_t>(1, std::min<uint64_t>((n_long + 1) / 2, (uint64_t)n_cu * 4));
-                        lstreams = (lstreams + 3) / 4 * 4;
-                        const double linstr = instr_per_row(lp.K, 64);
-                        work += (double)rows_long * lp.npass * linstr * cps;
-                        const double lcrit = (std::max<double>((double)rows_long / lstreams, (double)longest_long) + 64) *
-                                             lp.npass * linstr * 7.5; // raised priority: close to a wave alone
+                        // the long pairs have to be done by the time the bulk is
+                        const double bulk_cycles = std::max(work / simds, crit);
+                        if (!long_class_geometry(lq, longest_long, 0.8 * bulk_cycles, &lp)) continue;
+                        const uint64_t lspw = 4ull * (64 / lp.G);
+                        lstreams = std::max<uint64_t>(1, std::min<uint64_t>((n_long + 1) / 2, (uint64_t)n_cu * lspw));
+                        lstreams = (lstreams + lspw - 1) / lspw * lspw;
+                        const double linstr = instr_per_row(lp.K, lp.G);
+                        work += (double)rows_long / (64 / lp.G) * lp.npass * linstr * cps;
+                        const double lcrit = (std::max<double>((double)rows_long / lstreams, (double)longest_long) + lp.G) *
+                                             lp.npass * linstr * 7.5;
                         crit = std::max(crit, lcrit);
                     }
                     double cycles = std::max(work / simds, crit);
@@ -160,7 +182,7 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
                             wk->n_classes = 2;
                             wk->plan[1] = lp;
                             wk->plan[1].n_streams = (uint32_t)lstreams;
-                            wk->plan[1].workgroups = (int)(lstreams / 4);
+                            wk->plan[1].workgroups = (int)(lstreams / (4ull * (64 / lp.G)));
                             wk->plan[1].est_ms = ms;
                             wk->pair_begin[1] = 0;
                             wk->pair_end[1] = n_long;
