@@ -100,6 +100,8 @@ int swg_abi_version(void);
  * "max_waves" (0 auto | systolic: waves chained over the query, 1..16; diagonal:
  * waves per workgroup, multiple of 4), "group_lanes" (0 auto | 16 | 32 | 64),
  * "long_split" (-1 off | 0 auto | rows above which a pair joins the long class),
+ * "autotune" (1 default: on the first search of a query length the few geometries the cost model
+ * ranks best are timed on the device and the fastest is kept for that database | 0 model only),
  * "workgroups" (0 auto). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 

@@ -139,6 +139,8 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         if (value != 0 && value != 16 && value != 32 && value != 64)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "group_lanes must be 0, 16, 32 or 64");
         ctx->opt_group = value;
+    } else if (!strcmp(key, "autotune")) {
+        ctx->opt_autotune = value != 0;
     } else if (!strcmp(key, "long_split")) {
         if (value < -1) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "long_split must be -1 (off), 0 (auto) or a row count");
         ctx->opt_long_split = value;
@@ -390,6 +392,128 @@ static int ensure_scratch(swg_ctx *ctx, size_t dwords)
     return SWG_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// diagonal engine: make a work plan resident, launch it
+// ---------------------------------------------------------------------------
+static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
+{
+    uint32_t ncols = 0;
+    for (int c = 0; c < wk.n_classes; ++c) {
+        int rc = ensure_diag_layout(ctx, db, c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
+        if (rc != SWG_OK) return rc;
+        ncols = std::max<uint32_t>(ncols, (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
+    }
+    // both classes slice the same [col/4][32][4] profile
+    return ensure_profile_cols(ctx, 0, ncols, 2, (1ull << 31) ^ ncols);
+}
+
+// Launches the fill of one work plan.  Events: ev[1] before, ev[2] after on the main stream;
+// with a long class also ev[5] (bulk end) and ev[7] (long end).
+static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int go, int ge, bool *two_ends)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
+    *two_ends = false;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    if (wk.n_classes == 2) {
+        // fork: the long pairs start first, on their own stream, beside the bulk
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[6], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
+    }
+    for (int c = wk.n_classes - 1; c >= 0; --c) {
+        const SwgDiagLayout &L = db->diag[c];
+        const SwgDiagPlan &pl = wk.plan[c];
+        SwgDiagParams d;
+        memset(&d, 0, sizeof d);
+        d.tok = L.d_tok;
+        d.stream_off = L.d_stream_off;
+        d.stream_pairs = L.d_stream_pairs;
+        d.stream_pair_off = L.d_stream_pair_off;
+        d.n_streams = L.n_streams;
+        d.profile = ctx->d_profile[0];
+        d.scores = db->d_scores;
+        d.scratch = L.d_scratch;
+        d.npass = (uint32_t)pl.npass;
+        d.G = (uint32_t)pl.G;
+        d.go = g | (g << 16);
+        d.ge = e | (e << 16);
+        // wavefronts on the critical path get issue priority over the ones they share a SIMD
+        // with: all of the long class; in the bulk, streams that hold little more than one very
+        // long pair
+        const double mean_blocks = (double)L.total_blocks / std::max<uint32_t>(1, L.n_streams);
+        d.prio_blocks = c == 1 ? 0u
+                        : (double)L.max_stream_blocks > 1.1 * mean_blocks ? (uint32_t)(0.75 * (double)L.max_stream_blocks)
+                                                                          : 0xFFFFFFFFu;
+        HIP_TRY(ctx, swg_launch_diag(pl.variant, pl.npass > 1, pl.W, pl.workgroups, pl.lds_bytes, d,
+                                     c == 1 ? ctx->stream2 : s));
+    }
+    if (wk.n_classes == 2) {
+        // join; the end of the fill is the later of the two kernels' ends
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[7], 0));
+        *two_ends = true;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    return SWG_OK;
+}
+
+static int diag_fill_ms(swg_ctx *ctx, bool two_ends, double *out)
+{
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    *out = ms;
+    if (two_ends) {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[5]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[7]));
+        *out = std::max(*out, (double)std::max(a, b));
+    }
+    return SWG_OK;
+}
+
+// First search of a query length on a database: the cost model ranks the geometries, the few
+// best are timed once on this device (each is a complete, valid fill) and the fastest is kept.
+static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, SwgDiagWork *best)
+{
+    std::vector<SwgDiagWork> cands;
+    if (swg_plan_diag_candidates(db, lq, ctx->n_cu, 0, 0, 0, 0, true, &cands) <= 0) return SWG_ERR_ARG;
+    // distinct (K, G, W, split) among the best-ranked
+    std::vector<SwgDiagWork> pick;
+    for (const SwgDiagWork &c : cands) {
+        bool dup = false;
+        for (const SwgDiagWork &p : pick)
+            dup |= p.plan[0].K == c.plan[0].K && p.plan[0].G == c.plan[0].G && p.plan[0].W == c.plan[0].W &&
+                   p.n_classes == c.n_classes;
+        if (!dup) pick.push_back(c);
+        if (pick.size() >= 5) break;
+    }
+    const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
+    double best_ms = 1e300;
+    for (const SwgDiagWork &c : pick) {
+        int rc = prepare_diag(ctx, db, c);
+        if (rc != SWG_OK) return rc;
+        double ms_min = 1e300;
+        for (int rep = 0; rep < 2; ++rep) {
+            bool two = false;
+            HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, ctx->stream));
+            rc = launch_diag(ctx, db, c, go, ge, &two);
+            if (rc != SWG_OK) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            double ms = 0;
+            if ((rc = diag_fill_ms(ctx, two, &ms)) != SWG_OK) return rc;
+            ms_min = std::min(ms_min, ms);
+        }
+        if (ms_min < best_ms) {
+            best_ms = ms_min;
+            *best = c;
+            best->plan[0].est_ms = ms_min;
+        }
+    }
+    return SWG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // the hot path
 // ---------------------------------------------------------------------------
@@ -456,8 +580,20 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     SwgDiagWork wk;
     bool use_diag = false;
     if (bits == 16 && ctx->opt_engine != 1) {
-        use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
-                                      ctx->opt_long_split, ctx->opt_workgroups == 0, &wk) > 0;
+        const bool free_geometry = ctx->opt_cols == 0 && ctx->opt_group == 0 && ctx->opt_max_waves == 0 &&
+                                   ctx->opt_long_split == 0 && ctx->opt_workgroups == 0;
+        swg_db *mdb = const_cast<swg_db *>(db);
+        auto it = free_geometry ? mdb->tuned.find(lq) : mdb->tuned.end();
+        if (it != mdb->tuned.end()) {
+            wk = it->second;
+            use_diag = true;
+        } else if (free_geometry && ctx->opt_autotune && db->n_local >= 4096 && db->n_local <= (4u << 20)) {
+            use_diag = autotune_diag(ctx, mdb, lq, go, ge, &wk) == SWG_OK && wk.n_classes > 0;
+            if (use_diag) mdb->tuned[lq] = wk;
+        }
+        if (!use_diag)
+            use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
+                                          ctx->opt_long_split, ctx->opt_workgroups == 0, &wk) > 0;
         if (!use_diag && ctx->opt_engine == 2)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
         if (use_diag && ctx->opt_workgroups > 0) {
@@ -493,15 +629,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         if ((rc = ensure_scratch(ctx, npass32 > 1 ? per_wave * 16 * (size_t)ctx->n_cu : 0)) != SWG_OK) return rc;
     }
     if (use_diag) {
-        uint32_t ncols = 0;
-        uint64_t geom = 1ull << 31;
-        for (int c = 0; c < wk.n_classes; ++c) {
-            rc = ensure_diag_layout(ctx, const_cast<swg_db *>(db), c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
-            if (rc != SWG_OK) return rc;
-            ncols = std::max<uint32_t>(ncols, (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
-        }
-        geom ^= ncols; // both classes slice the same [col/4][32][4] profile
-        rc = ensure_profile_cols(ctx, 0, ncols, 2, geom);
+        rc = prepare_diag(ctx, const_cast<swg_db *>(db), wk);
     } else if (!(bits == 32 && use_diag32)) {
         rc = ensure_profile(ctx, main_pl);
     }
@@ -533,48 +661,9 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     p.scratch = ctx->d_scratch;
 
     bool two_ends = false;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     if (use_diag) {
-        const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
-        if (wk.n_classes == 2) {
-            // fork: the long pairs start first, on their own stream, beside the bulk
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[6], s));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
-        }
-        for (int c = wk.n_classes - 1; c >= 0; --c) {
-            const SwgDiagLayout &L = db->diag[c];
-            const SwgDiagPlan &pl = wk.plan[c];
-            SwgDiagParams d;
-            memset(&d, 0, sizeof d);
-            d.tok = L.d_tok;
-            d.stream_off = L.d_stream_off;
-            d.stream_pairs = L.d_stream_pairs;
-            d.stream_pair_off = L.d_stream_pair_off;
-            d.n_streams = L.n_streams;
-            d.profile = ctx->d_profile[0];
-            d.scores = db->d_scores;
-            d.scratch = L.d_scratch;
-            d.npass = (uint32_t)pl.npass;
-            d.G = (uint32_t)pl.G;
-            d.go = g | (g << 16);
-            d.ge = e | (e << 16);
-            // wavefronts on the critical path get issue priority over the ones they
-            // share a SIMD with: all of the long class; in the bulk, streams that hold
-            // little more than one very long pair
-            const double mean_blocks = (double)L.total_blocks / std::max<uint32_t>(1, L.n_streams);
-            d.prio_blocks = c == 1 ? 0u
-                            : (double)L.max_stream_blocks > 1.1 * mean_blocks ? (uint32_t)(0.75 * (double)L.max_stream_blocks)
-                                                                              : 0xFFFFFFFFu;
-            HIP_TRY(ctx, swg_launch_diag(pl.variant, pl.npass > 1, pl.W, pl.workgroups, pl.lds_bytes, d,
-                                         c == 1 ? ctx->stream2 : s));
-        }
-        if (wk.n_classes == 2) {
-            // join; the end of the fill is the later of the two kernels' ends
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream2));
-            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[7], 0));
-            two_ends = true;
-        }
+        if ((rc = launch_diag(ctx, db, wk, go, ge, &two_ends)) != SWG_OK) return rc;
     } else if (bits == 32 && use_diag32) {
         p.profile = ctx->d_profile[1];
         p.queue = db->d_counters + 0;
@@ -604,7 +693,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb;
         HIP_TRY(ctx, swg_launch_fill(bits, main_pl.variant, main_pl.W, main_pl.workgroups, p, s));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
     if (may_saturate) {
         HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, db->d_list,
                                                   db->d_counters + 1, s));
@@ -674,14 +763,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     }
 
     float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
-    st.fill_ms = ms;
-    if (two_ends) {
-        float a = 0.f, b = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[5]));
-        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[7]));
-        st.fill_ms = std::max(st.fill_ms, (double)std::max(a, b));
-    }
+    if ((rc = diag_fill_ms(ctx, two_ends, &st.fill_ms)) != SWG_OK) return rc;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     st.rescore_ms = may_saturate ? ms : 0.0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));

@@ -89,9 +89,10 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
     return ok;
 }
 
-int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                       long opt_long_split, bool allow_split, SwgDiagWork *wk)
+int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
+                             long opt_long_split, bool allow_split, std::vector<SwgDiagWork> *cands)
 {
+    cands->clear();
     const uint64_t n_pairs = swg_db_pair_count(db);
     if (n_pairs == 0) return 0;
     uint64_t longest = 0;
@@ -99,8 +100,6 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
     const bool have_long = allow_split && opt_long_split >= 0;
     const double simds = 4.0 * n_cu;
     const int groups[3] = {16, 32, 64};
-    double best_ms = 1e300;
-    wk->n_classes = 0;
     for (int v = 0; v < swg_num_diag_variants(); ++v) {
         const SwgKernelInfo info = swg_diag_variant_info(v);
         if (opt_cols > 0 && info.K != (int)opt_cols) continue;
@@ -163,8 +162,9 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
                     double cycles = std::max(work / simds, crit);
                     cycles *= 1.0 + 0.04 * (npass - 1); // profile reloads, pass barriers, edge spills
                     const double ms = cycles / 2.35e9 * 1e3;
-                    if (ms < best_ms) {
-                        best_ms = ms;
+                    {
+                        SwgDiagWork one;
+                        SwgDiagWork *wk = &one;
                         SwgDiagPlan &b = wk->plan[0];
                         b.variant = v;
                         b.K = info.K;
@@ -187,11 +187,24 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
                             wk->pair_begin[1] = 0;
                             wk->pair_end[1] = n_long;
                         }
+                        cands->push_back(one);
                     }
                 }
             }
         }
     }
+    std::stable_sort(cands->begin(), cands->end(),
+                     [](const SwgDiagWork &a, const SwgDiagWork &b) { return a.plan[0].est_ms < b.plan[0].est_ms; });
+    return (int)cands->size();
+}
+
+int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
+                       long opt_long_split, bool allow_split, SwgDiagWork *wk)
+{
+    std::vector<SwgDiagWork> c;
+    wk->n_classes = 0;
+    if (swg_plan_diag_candidates(db, lq, n_cu, opt_cols, opt_group, opt_waves, opt_long_split, allow_split, &c) > 0)
+        *wk = c[0];
     return wk->n_classes;
 }
 

@@ -4,6 +4,7 @@
 #include "../../include/swg.h"
 #include "swg_internal.h"
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,22 @@ struct SwgDiagLayout {
     uint64_t d_scratch_rows = 0;
 };
 
+struct SwgDiagPlan {
+    int variant, K, G, npass, W, workgroups;
+    uint32_t n_streams;
+    size_t lds_bytes;
+    double est_ms;
+};
+// The diagonal engine's work split: class 0 = the bulk of the pairs, class 1 = the few
+// longest ones, which would otherwise be the serial tail of the whole search.  The long
+// class runs beside the bulk on a second HIP stream with 64 lanes per pair and as few
+// columns per lane as cover the query, i.e. with the shortest possible chain per row.
+struct SwgDiagWork {
+    int n_classes = 0;
+    SwgDiagPlan plan[2];
+    uint64_t pair_begin[2] = {0, 0}, pair_end[2] = {0, 0};
+};
+
 struct swg_db {
     // host image
     size_t n_total = 0;             // sequences given to swg_db_pack
@@ -45,6 +62,7 @@ struct swg_db {
     std::vector<uint8_t> codes;     // residue bytes (index<<3) by sorted rank, back to back
     std::vector<uint64_t> code_off; // [n_bins*128+1]
     SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs
+    std::map<uint64_t, SwgDiagWork> tuned; // query length -> geometry that measured fastest on this device
     // device image (valid after swg_db_upload)
     int device = -1;
     uint32_t *d_packed = nullptr;
@@ -71,7 +89,7 @@ struct swg_ctx {
     // query
     std::vector<int8_t> query;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1;
     // device state
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;
@@ -91,25 +109,13 @@ int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
 void swg_db_release_device(swg_db *db);
 
 // swg_diag_host.cpp (host only)
-struct SwgDiagPlan {
-    int variant, K, G, npass, W, workgroups;
-    uint32_t n_streams;
-    size_t lds_bytes;
-    double est_ms;
-};
-// The diagonal engine's work split: class 0 = the bulk of the pairs, class 1 = the few
-// longest ones, which would otherwise be the serial tail of the whole search.  The long
-// class runs beside the bulk on a second HIP stream with 64 lanes per pair and as few
-// columns per lane as cover the query, i.e. with the shortest possible chain per row.
-struct SwgDiagWork {
-    int n_classes = 0;
-    SwgDiagPlan plan[2];
-    uint64_t pair_begin[2] = {0, 0}, pair_end[2] = {0, 0};
-};
 // geometry of both classes for one query length on one device; returns the number of
 // classes (0: the diagonal engine cannot run this with the given options)
 int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
                        long opt_long_split, bool allow_split, SwgDiagWork *wk);
+// every geometry the model considered, best estimate first (the autotuner times the first few)
+int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
+                             long opt_long_split, bool allow_split, std::vector<SwgDiagWork> *cands);
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
                            uint32_t streams_per_wg, SwgDiagLayout *out);
 uint64_t swg_db_pair_count(const swg_db *db);

@@ -189,6 +189,34 @@ def test_random_database_matches_oracle(swg, ctx, orc):
     db2.close()
 
 
+def test_autotuned_geometry_matches_oracle(swg, ctx, orc):
+    """>= 4096 sequences: the first search times the best-ranked geometries on the device and
+    keeps the fastest; every timed run and every later search must give the oracle's scores."""
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(77, 200)
+    flat, off = swg.synth_db(77, 6000, max_len=1500)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    db = swg.Database(flat, off).upload(ctx)
+    first, _, st1 = ctx.search(db)
+    again, hits, st2 = ctx.search(db, k=25)
+    assert np.array_equal(first, want) and np.array_equal(again, want)
+    assert hits == orc.topk(want, 25)
+    geom = lambda st: (st["cols_per_wave"], st["group_lanes"], st["waves"], st["long_pairs"])
+    assert geom(st1) == geom(st2)                 # the tuned plan is kept
+    ctx.set_option("autotune", 0)
+    model, _, _ = ctx.search(db)
+    ctx.set_option("autotune", 1)
+    assert np.array_equal(model, want)
+    q2 = swg.synth_query(78, 333)                 # another query length: tuned separately
+    ctx.set_query(q2)
+    other, _, _ = ctx.search(db)
+    assert np.array_equal(other, orc.score_db(q2, flat, off, sc.table(), -2, -1))
+    db.close()
+
+
 def test_high_similarity_rescore_matches_oracle(swg, ctx, orc):
     """Config-5-shaped: planted near-copies of a long query saturate int16 and are re-scored."""
     sc = swg.load_scoring("BLOSUM62")
