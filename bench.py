@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 systolic, 2 diagonal")
     ap.add_argument("--group", type=int, default=0, help="diagonal engine: lanes per sequence pair")
     ap.add_argument("--long-split", type=int, default=0, help="-1 off, 0 auto, else rows threshold of the long class")
+    ap.add_argument("--long-cols", type=int, default=0, help="experiment: columns per lane of the long class")
+    ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
@@ -103,6 +105,8 @@ def main():
     ctx.set_option("engine", args.engine)
     ctx.set_option("group_lanes", args.group)
     ctx.set_option("long_split", args.long_split)
+    ctx.set_option("long_cols", args.long_cols)
+    ctx.set_option("autotune", 0 if args.no_autotune else 1)
     db = swg.Database(flat, off).upload(ctx)
     residues = int(db.residues)
 
@@ -158,10 +162,15 @@ def main():
                 traffic = tj.get("config%d" % args.config, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # the binding roof is integer VALU, reported beside the (by construction tiny) HBM fraction
-        ops_per_cell = 5.5 if last["path_bits"] == 16 else 13.0
-        valu_peak = 256 * 4 * 32 * 2.4e9          # lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+        # The binding roof is integer VALU issue, reported beside the (by construction tiny) HBM
+        # fraction.  5 packed instructions per cell (10 per two cells); "datasheet" prices them at one
+        # wave64 instruction per 2 cycles per SIMD, "measured" at the 4.56 cycles this instruction
+        # class really takes on gfx950 (tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt).
+        ops_per_cell = 5.0 if last["path_bits"] == 16 else 12.0
+        simds = 256 * 4
         kernel_gcups = cells_local / (k_ms * 1e-3) / 1e9
+        peak_datasheet = simds * 64 / 2.0 * 2.4e9 / ops_per_cell / 1e9
+        peak_measured = simds * 64 / 4.56 * 2.35e9 / ops_per_cell / 1e9
         out = {
             "metric": "GCUPS (DP cell updates/s) at 1/2/4/8 MI355X; bit-exact max scores vs CPU ref",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -185,9 +194,11 @@ def main():
                 "kernel": ("swg_diag_kernel<%d>" % last["cols_per_wave"]) if last["engine"] == 2
                 else "swg_fill_kernel<CellsI%d>" % last["path_bits"], "kernel_ms": round(k_ms, 4),
                 "bytes_alg_per_launch": bytes_alg,
-                "binding_roof": {"bound": "valu_int", "kernel_gcups": round(kernel_gcups, 2),
-                                 "ops_per_cell": ops_per_cell,
-                                 "frac": round(kernel_gcups * 1e9 * ops_per_cell / valu_peak, 4)},
+                "binding_roof": {"bound": "valu_issue", "kernel_gcups": round(kernel_gcups, 2),
+                                 "instr_per_cell": ops_per_cell,
+                                 "peak_gcups_datasheet_issue": round(peak_datasheet, 1),
+                                 "peak_gcups_measured_issue": round(peak_measured, 1),
+                                 "frac_of_measured_issue_peak": round(kernel_gcups / peak_measured, 4)},
             },
             "kernel_ms": {"fill": round(k_ms, 4), "search_total": round(float(np.mean(total_ms)), 4),
                           "rescore": round(float(last["rescore_ms"]), 4), "topk_host": round(float(last["topk_ms"]), 4)},

@@ -128,6 +128,10 @@ int swg_set_query(swg_ctx *ctx, const int8_t *idx, size_t lq);
 int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n,
                 int shard_rank, int shard_count, swg_db **out);
 int swg_db_upload(swg_ctx *ctx, swg_db *db); /* H2D; db becomes resident on ctx's GPU */
+/* Packed-database file (host-only): the sorted, binned, dword-packed image of swg_db_pack,
+ * so a large database is ingested once; swg_db_load validates the structure it reads. */
+int swg_db_save(const swg_db *db, const char *path);
+int swg_db_load(const char *path, swg_db **out);
 void swg_db_free(swg_db *db);
 size_t swg_db_count(const swg_db *db);          /* sequences in this shard */
 size_t swg_db_total_count(const swg_db *db);    /* sequences given to swg_db_pack */

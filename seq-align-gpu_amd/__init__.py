@@ -33,7 +33,7 @@ SWG_ERR_STATE, SWG_ERR_RESIDUE, SWG_ERR_IO, SWG_ERR_NODEVICE = -4, -5, -6, -7
 ABI_SYMBOLS = [
     "swg_create", "swg_destroy", "swg_last_error", "swg_global_error", "swg_abi_version",
     "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_upload",
-    "swg_db_free", "swg_db_count", "swg_db_total_count", "swg_db_residues",
+    "swg_db_free", "swg_db_save", "swg_db_load", "swg_db_count", "swg_db_total_count", "swg_db_residues",
     "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_fill_batches16", "swg_hit_key",
     "swg_key_hit", "swg_topk_merge_keys",
     "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
@@ -109,6 +109,8 @@ _sig("swg_set_query", C.c_int, [_vp, _vp, C.c_size_t])
 _sig("swg_db_pack", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_vp)])
 _sig("swg_db_upload", C.c_int, [_vp, _vp])
 _sig("swg_db_free", None, [_vp])
+_sig("swg_db_save", C.c_int, [_vp, C.c_char_p])
+_sig("swg_db_load", C.c_int, [C.c_char_p, C.POINTER(_vp)])
 _sig("swg_db_count", C.c_size_t, [_vp])
 _sig("swg_db_total_count", C.c_size_t, [_vp])
 _sig("swg_db_residues", C.c_uint64, [_vp])
@@ -255,8 +257,13 @@ def topk_merge_keys(keys, k):
 class Database:
     """Host-packed database shard (swg_db); `upload(ctx)` makes it resident."""
 
-    def __init__(self, flat, offsets, shard_rank=0, shard_count=1):
+    def __init__(self, flat=None, offsets=None, shard_rank=0, shard_count=1, path=None):
         self.handle = None
+        if path is not None:            # load a packed-database file written by save()
+            h = _vp()
+            _check(lib.swg_db_load(path.encode(), C.byref(h)))
+            self.handle = h
+            return
         self._flat, fp = _i8(flat)
         self._off = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = self._off.size - 1
@@ -272,6 +279,9 @@ class Database:
 
     def order(self):
         return np.ctypeslib.as_array(lib.swg_db_order(self.handle), shape=(self.count,)).copy()
+
+    def save(self, path):
+        _check(lib.swg_db_save(self.handle, path.encode()))
 
     def upload(self, ctx):
         _check(lib.swg_db_upload(ctx.handle, self.handle), ctx.handle)

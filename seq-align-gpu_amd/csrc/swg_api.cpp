@@ -112,6 +112,7 @@ extern "C" void swg_destroy(swg_ctx *ctx)
     (void)hipFree(ctx->d_query);
     (void)hipFree(ctx->d_profile[0]);
     (void)hipFree(ctx->d_profile[1]);
+    (void)hipFree(ctx->d_profile[2]);
     (void)hipFree(ctx->d_scratch);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -139,6 +140,9 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         if (value != 0 && value != 16 && value != 32 && value != 64)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "group_lanes must be 0, 16, 32 or 64");
         ctx->opt_group = value;
+    } else if (!strcmp(key, "long_cols")) {
+        extern long g_swg_long_cols;
+        g_swg_long_cols = value;
     } else if (!strcmp(key, "autotune")) {
         ctx->opt_autotune = value != 0;
     } else if (!strcmp(key, "long_split")) {
@@ -311,6 +315,7 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
 
 static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom)
 {
+    const int chunk_cols = which == 2 ? 2 : 4;
     const size_t bytes = (size_t)ncols * 32 * elem_size;
     const uint64_t tag = (ctx->epoch << 32) ^ geom;
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
@@ -322,7 +327,7 @@ static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem
         ctx->d_profile_cap[which] = bytes;
     }
     HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols,
-                                          elem_size, ctx->d_profile[which], ctx->stream));
+                                          elem_size, chunk_cols, ctx->d_profile[which], ctx->stream));
     ctx->profile_tag[which] = tag;
     return SWG_OK;
 }
@@ -396,16 +401,24 @@ static int ensure_scratch(swg_ctx *ctx, size_t dwords)
 // ---------------------------------------------------------------------------
 // diagonal engine: make a work plan resident, launch it
 // ---------------------------------------------------------------------------
+static int diag_profile_slot(const SwgDiagPlan &pl) { return pl.K % 4 == 0 ? 0 : 2; }
+
 static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
 {
-    uint32_t ncols = 0;
+    uint32_t ncols[3] = {0, 0, 0};
     for (int c = 0; c < wk.n_classes; ++c) {
         int rc = ensure_diag_layout(ctx, db, c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
         if (rc != SWG_OK) return rc;
-        ncols = std::max<uint32_t>(ncols, (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
+        const int slot = diag_profile_slot(wk.plan[c]);
+        ncols[slot] = std::max<uint32_t>(ncols[slot], (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
     }
-    // both classes slice the same [col/4][32][4] profile
-    return ensure_profile_cols(ctx, 0, ncols, 2, (1ull << 31) ^ ncols);
+    // classes with the same chunking slice the same [col/ch][32][ch] profile
+    for (int slot = 0; slot < 3; slot += 2)
+        if (ncols[slot]) {
+            int rc = ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ncols[slot]);
+            if (rc != SWG_OK) return rc;
+        }
+    return SWG_OK;
 }
 
 // Launches the fill of one work plan.  Events: ev[1] before, ev[2] after on the main stream;
@@ -431,7 +444,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
         d.stream_pairs = L.d_stream_pairs;
         d.stream_pair_off = L.d_stream_pair_off;
         d.n_streams = L.n_streams;
-        d.profile = ctx->d_profile[0];
+        d.profile = ctx->d_profile[diag_profile_slot(pl)];
         d.scores = db->d_scores;
         d.scratch = L.d_scratch;
         d.npass = (uint32_t)pl.npass;
@@ -485,9 +498,11 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
         bool dup = false;
         for (const SwgDiagWork &p : pick)
             dup |= p.plan[0].K == c.plan[0].K && p.plan[0].G == c.plan[0].G && p.plan[0].W == c.plan[0].W &&
-                   p.n_classes == c.n_classes;
+                   p.n_classes == c.n_classes &&
+                   (c.n_classes < 2 || (p.plan[1].K == c.plan[1].K && p.plan[1].G == c.plan[1].G &&
+                                        p.pair_end[1] == c.pair_end[1]));
         if (!dup) pick.push_back(c);
-        if (pick.size() >= 5) break;
+        if (pick.size() >= 8) break;
     }
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     double best_ms = 1e300;

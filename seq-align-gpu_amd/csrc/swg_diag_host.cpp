@@ -49,6 +49,8 @@ static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 18.0 : 
 
 // Long class: the cheapest geometry (instructions per pair-row, column padding included)
 // whose longest chain still finishes within `budget_cycles`; if none does, the shortest chain.
+long g_swg_long_cols = 0; // experiment switch: restrict the long class to this K (0 = free)
+
 static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_cycles, SwgDiagPlan *lp)
 {
     bool ok = false, ok_fit = false;
@@ -57,6 +59,7 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
     const int groups[2] = {32, 64};
     for (int v = 0; v < swg_num_diag_variants(); ++v) {
         const SwgKernelInfo info = swg_diag_variant_info(v);
+        if (g_swg_long_cols > 0 && info.K != (int)g_swg_long_cols) continue;
         for (int gi = 0; gi < 2; ++gi) {
             const int G = groups[gi];
             const size_t cols = (size_t)G * info.K;
@@ -121,13 +124,15 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                 const double cps = kCyclesPerInstr[eff_wps];
                 const uint64_t spw = (uint64_t)W * NG;
                 const uint64_t hw_streams = (uint64_t)n_cu * per_cu * spw;
-                for (int split = 0; split <= (have_long ? 1 : 0); ++split) {
+                for (int split = 0; split <= (have_long ? 3 : 0); ++split) {
                     uint64_t n_long = 0, rows_long = 0, longest_bulk = longest, longest_long = 0;
                     uint64_t streams0 = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, n_pairs));
                     streams0 = (streams0 + spw - 1) / spw * spw;
                     if (split) {
+                        if (split == 3 && opt_long_split > 0) continue;
+                        const double frac = split == 3 ? 0.6 : 0.33;
                         uint64_t thr = opt_long_split > 0 ? (uint64_t)opt_long_split
-                                                          : (uint64_t)(0.33 * (double)rows_all / (double)streams0);
+                                                          : (uint64_t)(frac * (double)rows_all / (double)streams0);
                         thr = std::max<uint64_t>(thr, 64);
                         if (longest <= thr) continue;
                         n_long = swg_db_pairs_longer_than(db, thr);
@@ -149,7 +154,17 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     if (split) {
                         // the long pairs have to be done by the time the bulk is
                         const double bulk_cycles = std::max(work / simds, crit);
-                        if (!long_class_geometry(lq, longest_long, 0.8 * bulk_cycles, &lp)) continue;
+                        if (split == 2) {
+                            // the bulk's own geometry (no extra column padding), own streams, raised priority
+                            lp.variant = v;
+                            lp.K = info.K;
+                            lp.G = G;
+                            lp.npass = npass;
+                            lp.W = 4;
+                            lp.lds_bytes = lds;
+                        } else if (!long_class_geometry(lq, longest_long, 0.8 * bulk_cycles, &lp)) {
+                            continue;
+                        }
                         const uint64_t lspw = 4ull * (64 / lp.G);
                         lstreams = std::max<uint64_t>(1, std::min<uint64_t>((n_long + 1) / 2, (uint64_t)n_cu * lspw));
                         lstreams = (lstreams + lspw - 1) / lspw * lspw;

@@ -79,8 +79,9 @@ hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, s
 
 // profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
 // col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.
+// chunk_cols: columns per chunk, [col/chunk][32][chunk] (4 everywhere except diagonal K % 4 == 2)
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
-                                    uint32_t lq, uint32_t ncols, int elem_size,
+                                    uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols,
                                     uint8_t *d_profile, hipStream_t stream);
 
 // Appends every slot id whose int16 score saturated (== 32767) to list.

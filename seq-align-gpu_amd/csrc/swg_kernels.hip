@@ -425,7 +425,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 #define DPP_WAVE_SHR1 0x138
 
 template <int K> struct CellsDiag {
-    static constexpr int CHUNK = 256;
+    // columns per profile chunk: 4 (one ds_read_b64 per sequence) when K allows it, else 2
+    // (ds_read_b32); a chunk is [32 residues][CH] int16
+    static constexpr int CH = (K % 4 == 0) ? 4 : 2;
+    static constexpr int CHUNK = 32 * CH * 2;
     uint32_t M[K], G[K], A[K];
     uint32_t best, mdl;
 
@@ -445,17 +448,24 @@ template <int K> struct CellsDiag {
         uint32_t gl = pk_sub_u16_sat(em, go);
         uint32_t bl = eb;
 #pragma unroll
-        for (int c = 0; c < K / 4; ++c) {
-            const uint2 wx = *reinterpret_cast<const uint2 *>(prof + offx + c * CHUNK);
-            const uint2 wy = *reinterpret_cast<const uint2 *>(prof + offy + c * CHUNK);
-            uint32_t s[4];
-            s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
-            s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
-            s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
-            s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
+        for (int c = 0; c < K / CH; ++c) {
+            uint32_t s[CH];
+            if constexpr (CH == 4) {
+                const uint2 wx = *reinterpret_cast<const uint2 *>(prof + offx + c * CHUNK);
+                const uint2 wy = *reinterpret_cast<const uint2 *>(prof + offy + c * CHUNK);
+                s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
+                s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
+                s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
+                s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
+            } else {
+                const uint32_t wx = *reinterpret_cast<const uint32_t *>(prof + offx + c * CHUNK);
+                const uint32_t wy = *reinterpret_cast<const uint32_t *>(prof + offy + c * CHUNK);
+                s[0] = __builtin_amdgcn_perm(wy, wx, 0x05040100u);
+                s[1] = __builtin_amdgcn_perm(wy, wx, 0x07060302u);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = 4 * c + u;
+            for (int u = 0; u < CH; ++u) {
+                const int k = CH * c + u;
                 const uint32_t t = pk_add_i16_sat(md, s[u]);
                 md = M[k];
                 const uint32_t a = pk_max_i16(G[k], pk_sub_u16_sat(A[k], ge));
@@ -503,7 +513,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
     const uint32_t rows = nblk * 4u;
     const uint2 *tp = p.tok + boff;
     uint2 *sp = p.scratch + boff * 4u;
-    const uint32_t base = (uint32_t)g * (K / 4) * 256u;
+    constexpr int CH = CellsDiag<K>::CH;
+    const uint32_t base = (uint32_t)g * (K / CH) * CellsDiag<K>::CHUNK;
     const uint32_t slice = (uint32_t)G * K * 64u;
     const int npass = MULTIPASS ? (int)p.npass : 1;
 
@@ -565,8 +576,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                 // reset rows: gap magnitudes of all ones wipe A/G/B, two such rows wipe M
                 const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
                 cells.best &= ~fm;
-                const uint2 e = cells.row(smem, base + (tok & 0xF8u), base + ((tok >> 8) & 0xF8u), em, eb,
-                                          p.go | fm, p.ge | fm);
+                // residue byte = index<<3 = byte offset of its row in a 4-column chunk (halved for 2)
+                const uint32_t ox = CH == 4 ? (tok & 0xF8u) : ((tok >> 1) & 0x7Cu);
+                const uint32_t oy = CH == 4 ? ((tok >> 8) & 0xF8u) : ((tok >> 9) & 0x7Cu);
+                const uint2 e = cells.row(smem, base + ox, base + oy, em, eb, p.go | fm, p.ge | fm);
                 m_out = e.x;
                 b_out = e.y;
                 c_out = pk_max_i16(cin, cells.best);
@@ -602,14 +615,14 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 // small kernels
 // ---------------------------------------------------------------------------
 __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
-                                         uint32_t ncols, int elem_size, uint8_t *out)
+                                         uint32_t ncols, int elem_size, uint32_t ch, uint8_t *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (col, code)
     if (t >= ncols * 32u) return;
     const uint32_t col = t >> 5, code = t & 31u;
     const bool pad = (col >= lq) || (code == 0u);
     const int v = pad ? 0 : (int)sub[(int)query[col] * 32 + (int)code];
-    const size_t e = (size_t)(col >> 2) * 128u + code * 4u + (col & 3u);
+    const size_t e = (size_t)(col / ch) * (32u * ch) + code * ch + (col % ch); // [col/ch][32][ch]
     if (elem_size == 2)
         reinterpret_cast<int16_t *>(out)[e] = pad ? (int16_t)-32768 : (int16_t)v;
     else
@@ -944,6 +957,7 @@ const DiagVariant *diag_variants(int *n)
 {
     static const DiagVariant v[] = {
         make_diag<24, 16>(), make_diag<12, 16>(), make_diag<8, 16>(), make_diag<16, 16>(), make_diag<32, 12>(),
+        make_diag<6, 16>(),  make_diag<10, 16>(),
     };
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
@@ -1022,12 +1036,12 @@ hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups, const S
 }
 
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, uint32_t lq,
-                                    uint32_t ncols, int elem_size, uint8_t *d_profile,
+                                    uint32_t ncols, int elem_size, int chunk_cols, uint8_t *d_profile,
                                     hipStream_t stream)
 {
     const uint32_t n = ncols * 32u;
     hipLaunchKernelGGL(swg_build_profile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_sub,
-                       d_query, lq, ncols, elem_size, d_profile);
+                       d_query, lq, ncols, elem_size, (uint32_t)chunk_cols, d_profile);
     return hipGetLastError();
 }
 

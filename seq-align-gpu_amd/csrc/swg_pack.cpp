@@ -139,6 +139,110 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
     return SWG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// packed database file: the host image of a swg_db, written once (sorting, binning and
+// dword-packing are the expensive part of ingest), loaded with plain reads afterwards
+// ---------------------------------------------------------------------------
+namespace {
+const char kMagic[8] = {'S', 'W', 'G', 'D', 'B', '0', '1', '\0'};
+struct FileHeader {
+    char magic[8];
+    uint64_t n_total, n_local, n_bins, max_nblk, residues, rows_padded;
+    uint64_t n_packed, n_codes;
+};
+template <class T> bool put(FILE *f, const std::vector<T> &v)
+{
+    return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size();
+}
+template <class T> bool get(FILE *f, std::vector<T> &v, size_t n)
+{
+    v.resize(n);
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+} // namespace
+
+extern "C" int swg_db_save(const swg_db *db, const char *path)
+{
+    if (!db || !path) return swg_set_global_error(SWG_ERR_ARG, "swg_db_save: NULL argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return swg_set_global_error(SWG_ERR_IO, "swg_db_save: cannot write %s", path);
+    FileHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, kMagic, 8);
+    h.n_total = db->n_total;
+    h.n_local = db->n_local;
+    h.n_bins = db->n_bins;
+    h.max_nblk = db->max_nblk;
+    h.residues = db->residues;
+    h.rows_padded = db->rows_padded;
+    h.n_packed = db->packed.size();
+    h.n_codes = db->codes.size();
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && put(f, db->bin_off) && put(f, db->bin_nblk) && put(f, db->order) &&
+              put(f, db->lens) && put(f, db->code_off) && put(f, db->codes) && put(f, db->packed);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return swg_set_global_error(SWG_ERR_IO, "swg_db_save: short write to %s", path);
+    return SWG_OK;
+}
+
+extern "C" int swg_db_load(const char *path, swg_db **out)
+{
+    if (!path || !out) return swg_set_global_error(SWG_ERR_ARG, "swg_db_load: NULL argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return swg_set_global_error(SWG_ERR_IO, "swg_db_load: cannot read %s", path);
+    FileHeader h;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kMagic, 8) != 0) {
+        fclose(f);
+        return swg_set_global_error(SWG_ERR_IO, "swg_db_load: %s is not a packed database", path);
+    }
+    const uint64_t ns = h.n_bins * SWG_BIN;
+    if (h.n_local > ns || h.n_bins > 0xFFFFFFFFull / SWG_BIN || h.n_local > h.n_total) {
+        fclose(f);
+        return swg_set_global_error(SWG_ERR_IO, "swg_db_load: inconsistent header in %s", path);
+    }
+    swg_db *db = new (std::nothrow) swg_db();
+    if (!db) {
+        fclose(f);
+        return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_load: out of memory");
+    }
+    bool ok = false;
+    try {
+        db->n_total = h.n_total;
+        db->n_local = h.n_local;
+        db->n_bins = (uint32_t)h.n_bins;
+        db->max_nblk = (uint32_t)h.max_nblk;
+        db->residues = h.residues;
+        db->rows_padded = h.rows_padded;
+        ok = get(f, db->bin_off, h.n_bins) && get(f, db->bin_nblk, h.n_bins) && get(f, db->order, ns) &&
+             get(f, db->lens, ns) && get(f, db->code_off, ns + 1) && get(f, db->codes, h.n_codes) &&
+             get(f, db->packed, h.n_packed);
+    } catch (const std::bad_alloc &) {
+        ok = false;
+    }
+    fclose(f);
+    // cheap structural checks: nothing read from the file is trusted as an index unchecked
+    if (ok) {
+        uint64_t dwords = 0;
+        for (size_t b = 0; b < db->n_bins && ok; ++b) {
+            ok = db->bin_off[b] == dwords && db->bin_nblk[b] >= 1 && db->bin_nblk[b] <= db->max_nblk;
+            dwords += (uint64_t)db->bin_nblk[b] * SWG_BIN;
+        }
+        ok = ok && dwords == db->packed.size() && db->code_off[ns] == db->codes.size() &&
+             db->residues == db->codes.size() && db->rows_padded == dwords * SWG_ROWS_PER_BLK;
+        for (size_t s = 0; s < ns && ok; ++s) {
+            ok = db->code_off[s + 1] - db->code_off[s] == db->lens[s] &&
+                 (db->order[s] == 0xFFFFFFFFu || db->order[s] < db->n_total) &&
+                 db->lens[s] <= (uint64_t)db->bin_nblk[s / SWG_BIN] * SWG_ROWS_PER_BLK;
+        }
+    }
+    if (!ok) {
+        delete db;
+        return swg_set_global_error(SWG_ERR_IO, "swg_db_load: %s is truncated or corrupt", path);
+    }
+    *out = db;
+    return SWG_OK;
+}
+
 extern "C" void swg_db_free(swg_db *db)
 {
     if (!db) return;

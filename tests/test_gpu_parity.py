@@ -87,7 +87,8 @@ def test_overflow_is_detected_and_rescored(swg, ctx):
 
 
 @pytest.mark.parametrize("cols,group,waves", [(24, 16, 16), (12, 32, 16), (8, 64, 16), (12, 64, 8), (16, 16, 4),
-                                              (32, 64, 12), (8, 16, 4), (8, 32, 8), (24, 64, 4)])
+                                              (32, 64, 12), (8, 16, 4), (8, 32, 8), (24, 64, 4),
+                                              (6, 64, 16), (10, 32, 8), (6, 16, 4)])
 def test_diagonal_geometry_does_not_change_scores(swg, ctx, cols, group, waves):
     """Columns per lane, lanes per sequence pair, occupancy and the number of query passes
     (1 .. 24 here) are invisible in the result of the diagonal engine."""
@@ -210,6 +211,13 @@ def test_autotuned_geometry_matches_oracle(swg, ctx, orc):
     model, _, _ = ctx.search(db)
     ctx.set_option("autotune", 1)
     assert np.array_equal(model, want)
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:      # a database loaded from its packed file searches the same
+        db.save(os.path.join(d, "db.swgdb"))
+        db2 = swg.Database(path=os.path.join(d, "db.swgdb")).upload(ctx)
+        loaded, _, _ = ctx.search(db2)
+        assert np.array_equal(loaded, want)
+        db2.close()
     q2 = swg.synth_query(78, 333)                 # another query length: tuned separately
     ctx.set_query(q2)
     other, _, _ = ctx.search(db)

@@ -162,6 +162,26 @@ def test_pack_orders_bins_and_validates(swg):
     assert empty.count == 0
 
 
+def test_packed_database_file_roundtrip(swg, tmp_path):
+    flat, off = swg.synth_db(5, 700, max_len=300)
+    db = swg.Database(flat, off, 1, 2)
+    path = str(tmp_path / "shard.swgdb")
+    db.save(path)
+    back = swg.Database(path=path)
+    assert (back.count, back.total_count, back.residues, back.packed_bytes) == \
+           (db.count, db.total_count, db.residues, db.packed_bytes)
+    assert np.array_equal(back.order(), db.order())
+    raw = open(path, "rb").read()
+    for bad in (raw[:100], raw[:-7], b"NOTADB00" + raw[8:], raw[:40] + b"\xff" * 8 + raw[48:]):
+        p2 = tmp_path / "bad.swgdb"
+        p2.write_bytes(bad)
+        with pytest.raises(swg.SwgError) as e:
+            swg.Database(path=str(p2))
+        assert e.value.code == swg.SWG_ERR_IO
+    with pytest.raises(swg.SwgError):
+        swg.Database(path=str(tmp_path / "missing.swgdb"))
+
+
 def test_synthetic_data_is_deterministic_and_shaped(swg):
     f1, o1 = swg.synth_db(0x5EED0002, 2000)
     f2, o2 = swg.synth_db(0x5EED0002, 2000)
