@@ -60,6 +60,10 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
     for (int v = 0; v < swg_num_diag_variants(); ++v) {
         const SwgKernelInfo info = swg_diag_variant_info(v);
         if (g_swg_long_cols > 0 && info.K != (int)g_swg_long_cols) continue;
+        // 2-column-chunk instantiations (K % 4 == 2) measured slower as the long class than the
+        // next multiple of 4 despite fewer instructions (more, narrower LDS reads per step on a
+        // latency-bound chain): only on request
+        if (g_swg_long_cols == 0 && info.K % 4 != 0) continue;
         for (int gi = 0; gi < 2; ++gi) {
             const int G = groups[gi];
             const size_t cols = (size_t)G * info.K;
