@@ -283,3 +283,84 @@ def test_errors_are_codes_not_crashes(swg, ctx):
     empty = swg.Database(np.zeros(0, np.int8), np.zeros(1, np.uint64)).upload(ctx)
     scores, hits, st = ctx.search(empty, k=5)
     assert scores.size == 0 and hits == [] and st["cells"] == 0
+
+
+def test_full_size_config2_properties(swg, ctx, orc):
+    """BASELINE config 2 at full size (367 aa vs 100k sequences, PAM250) is too big for the scalar
+    oracle, so the HIP path is pinned by size-independent properties of the recurrence:
+      * three independent code paths agree per sequence (diagonal int16, systolic int16, exact int32);
+      * doubling every substitution score and both gap scores doubles every score;
+      * reversing the query and every database sequence leaves every score unchanged;
+      * a database copy of the query scores sum(S[q_i][q_i]);
+      * top-K equals the best K of the full score vector (ties by lower index);
+    plus the oracle itself on an evenly spaced sample of 600 sequences."""
+    sc = swg.load_scoring("PAM250")
+    tab = sc.table()
+    q = swg.synth_query(0x5EED0002, 367)
+    flat, off = swg.synth_db(0x5EED0002, 100000)
+    lens = np.diff(off.astype(np.int64))
+    # append the query itself as one more database sequence
+    flat = np.concatenate([flat, q])
+    off = np.concatenate([off, [off[-1] + len(q)]]).astype(np.uint64)
+    n = len(off) - 1
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    db = swg.Database(flat, off).upload(ctx)
+    base, hits, st = ctx.search(db, k=100)
+    assert st["engine"] == 2 and st["path_bits"] == 16
+    # independent paths
+    ctx.set_option("engine", 1)
+    assert np.array_equal(ctx.search(db)[0], base)
+    ctx.set_option("engine", 0)
+    ctx.set_option("force_bits", 32)
+    assert np.array_equal(ctx.search(db)[0], base)
+    ctx.set_option("force_bits", 0)
+    # self score and top-K
+    assert base[n - 1] == sum(int(tab[a, a]) for a in q) and hits[0] == (int(base[n - 1]), n - 1)
+    order = np.lexsort((np.arange(n), -base.astype(np.int64)))[:100]
+    assert hits == [(int(base[i]), int(i)) for i in order]
+    # oracle on a sample
+    sample = np.linspace(0, n - 1, 600).astype(np.int64)
+    s_off = np.zeros(len(sample) + 1, dtype=np.uint64)
+    s_off[1:] = np.cumsum([int(off[i + 1] - off[i]) for i in sample])
+    s_flat = np.concatenate([flat[int(off[i]):int(off[i + 1])] for i in sample])
+    assert np.array_equal(orc.score_db(q, s_flat, s_off, tab, -2, -1), base[sample])
+    # linearity: 2*S, 2*gaps -> 2*scores
+    ctx.set_scoring((tab.astype(np.int16) * 2).astype(np.int8), -4, -2)
+    assert np.array_equal(ctx.search(db)[0], 2 * base)
+    # reversal symmetry
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q[::-1].copy())
+    rflat = np.concatenate([flat[int(off[i]):int(off[i + 1])][::-1] for i in range(n)])
+    rdb = swg.Database(rflat, off).upload(ctx)
+    assert np.array_equal(ctx.search(rdb)[0], base)
+    rdb.close()
+    db.close()
+
+
+def test_long_tail_database(swg, ctx, orc):
+    """Swiss-Prot-like tail: a 35,000-residue sequence among short ones (one very long pair,
+    odd sequence count, lengths 1 and 2 present), query longer than one pass of some geometries."""
+    sc = swg.load_scoring("BLOSUM62")
+    rng = np.random.default_rng(9)
+    q = swg.synth_query(5, 500)
+    lens = [35000, 1, 2, 7000] + [int(v) for v in rng.integers(20, 900, size=297)]
+    seqs = [swg.synth_query(100 + i, L) for i, L in enumerate(lens)]
+    flat = np.concatenate(seqs)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    for opts in ({}, {"engine": 1}, {"force_bits": 32}, {"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4},
+                 {"long_split": 3000}, {"long_split": -1, "cols_per_wave": 6, "group_lanes": 64, "max_waves": 8}):
+        _reset_options(ctx)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        db = swg.Database(flat, off).upload(ctx)
+        got, hits, st = ctx.search(db, k=5)
+        assert np.array_equal(got, want), (opts, st)
+        assert hits == orc.topk(want, 5)
+        db.close()
+    _reset_options(ctx)
