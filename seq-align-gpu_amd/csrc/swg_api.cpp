@@ -52,6 +52,22 @@ int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
                                      __FILE__, __LINE__);                                       \
     } while (0)
 
+// Wait for everything queued on the stream by polling an event from user space.  A blocking
+// hipStreamSynchronize may put the thread to sleep; on a busy host the wake-up alone can cost
+// milliseconds per search, several times the fill itself.
+static hipError_t spin_sync(swg_ctx *ctx, hipStream_t s)
+{
+    hipError_t e = hipEventRecord(ctx->ev_done, s);
+    if (e != hipSuccess) return e;
+    for (;;) {
+        e = hipEventQuery(ctx->ev_done);
+        if (e != hipErrorNotReady) return e;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
 extern "C" const char *swg_last_error(const swg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 extern "C" const char *swg_global_error(void) { return g_err.c_str(); }
 extern "C" int swg_abi_version(void) { return SWG_ABI_VERSION; }
@@ -91,6 +107,7 @@ extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
             HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
         }
         for (auto &ev : ctx->ev) HIP_TRY(ctx, hipEventCreate(&ev));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
         HIP_TRY(ctx, hipMalloc(&ctx->d_sub, 32 * 32));
         return SWG_OK;
     }();
@@ -116,6 +133,7 @@ extern "C" void swg_destroy(swg_ctx *ctx)
     (void)hipFree(ctx->d_scratch);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -724,7 +742,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
             // usually none, then nothing is launched; a few long ones get a whole CU each
             uint32_t n_sat = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&n_sat, db->d_counters + 1, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));
+            HIP_TRY(ctx, spin_sync(ctx, s));
             if (n_sat > 0) {
                 int W = (int)((n_sat + (uint32_t)ctx->n_cu - 1) / (uint32_t)ctx->n_cu);
                 W = std::min(16, std::max(4, (W + 3) / 4 * 4));
@@ -763,17 +781,17 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipMemcpyAsync(h_counters, db->d_counters, sizeof h_counters, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, spin_sync(ctx, s));
     bool cand_ok = dev_topk && h_counters[5] == 0 && h_counters[3] <= SWG_TOPK_CAND_CAP;
     if (cand_ok && h_counters[3] > first_chunk) {
         HIP_TRY(ctx, hipMemcpyAsync(h_cand.data() + first_chunk, db->d_keys + first_chunk,
                                     (h_counters[3] - first_chunk) * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        HIP_TRY(ctx, spin_sync(ctx, s));
     }
     if (dev_topk && !cand_ok) { // threshold beyond the histogram or too many ties: select on the host
         h_scores.resize(n_slots);
         HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        HIP_TRY(ctx, spin_sync(ctx, s));
         need_scores = true;
     }
 

@@ -100,6 +100,7 @@ struct swg_ctx {
     uint64_t epoch = 1;               // bumps whenever scoring or query change
     uint32_t *d_scratch = nullptr;
     size_t d_scratch_cap = 0; // dwords
+    hipEvent_t ev_done = nullptr; // polled from user space instead of a blocking stream sync
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -483,6 +483,12 @@ template <int K> struct CellsDiag {
     }
 };
 
+template <int CTRL> DEVINL uint32_t dpp_zero(uint32_t src)
+{
+    // lanes without a source lane get 0 (bound_ctrl): no v_mov to set up an old value
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xf, 0xf, true);
+}
+
 template <int CTRL> DEVINL uint32_t dpp_keep(uint32_t keep, uint32_t src)
 {
     // lanes without a source lane keep `keep`
@@ -553,14 +559,14 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                 uint32_t em, eb, cin;
                 if (G == 16) {
                     tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
-                    em = dpp_keep<DPP_ROW_SHR1>(lm, m_out);
-                    eb = dpp_keep<DPP_ROW_SHR1>(lb, b_out);
-                    cin = dpp_keep<DPP_ROW_SHR1>(0u, c_out);
+                    em = MULTIPASS ? dpp_keep<DPP_ROW_SHR1>(lm, m_out) : dpp_zero<DPP_ROW_SHR1>(m_out);
+                    eb = MULTIPASS ? dpp_keep<DPP_ROW_SHR1>(lb, b_out) : dpp_zero<DPP_ROW_SHR1>(b_out);
+                    cin = dpp_zero<DPP_ROW_SHR1>(c_out);
                 } else {
                     const uint32_t t0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
-                    const uint32_t t1 = dpp_keep<DPP_WAVE_SHR1>(lm, m_out);
-                    const uint32_t t2 = dpp_keep<DPP_WAVE_SHR1>(lb, b_out);
-                    const uint32_t t3 = dpp_keep<DPP_WAVE_SHR1>(0u, c_out);
+                    const uint32_t t1 = MULTIPASS ? dpp_keep<DPP_WAVE_SHR1>(lm, m_out) : dpp_zero<DPP_WAVE_SHR1>(m_out);
+                    const uint32_t t2 = MULTIPASS ? dpp_keep<DPP_WAVE_SHR1>(lb, b_out) : dpp_zero<DPP_WAVE_SHR1>(b_out);
+                    const uint32_t t3 = dpp_zero<DPP_WAVE_SHR1>(c_out);
                     if (G == 32) { // lane 32 starts a group too
                         tok = leader ? fresh : t0;
                         em = leader ? lm : t1;
@@ -573,27 +579,33 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                         cin = t3;
                     }
                 }
-                // reset rows: gap magnitudes of all ones wipe A/G/B, two such rows wipe M
-                const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
-                cells.best &= ~fm;
                 // residue byte = index<<3 = byte offset of its row in a 4-column chunk (halved for 2)
                 const uint32_t ox = CH == 4 ? (tok & 0xF8u) : ((tok >> 1) & 0x7Cu);
                 const uint32_t oy = CH == 4 ? ((tok >> 8) & 0xF8u) : ((tok >> 9) & 0x7Cu);
-                const uint2 e = cells.row(smem, base + ox, base + oy, em, eb, p.go | fm, p.ge | fm);
+                // reset / last rows are rare: one wave-uniform test keeps their bookkeeping out of
+                // the common step (the recurrence itself is issued once, with per-lane gap operands)
+                const bool special = __builtin_amdgcn_ballot_w64((tok & (SWG_TOK_RESET | SWG_TOK_LAST)) != 0u) != 0ull;
+                uint32_t go_t = p.go, ge_t = p.ge;
+                if (special) {
+                    // reset rows: gap magnitudes of all ones wipe A/G/B, two such rows wipe M
+                    const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
+                    cells.best &= ~fm;
+                    go_t |= fm;
+                    ge_t |= fm;
+                }
+                const uint2 e = cells.row(smem, base + ox, base + oy, em, eb, go_t, ge_t);
+                c_out = pk_max_i16(cin, cells.best);
+                if (special && tail && (tok & SWG_TOK_LAST)) {
+                    const uint32_t pr = p.stream_pairs[pair0 + done];
+                    atomicMax(p.scores + 2u * pr, (int)(c_out & 0xFFFFu));
+                    atomicMax(p.scores + 2u * pr + 1u, (int)(c_out >> 16));
+                    ++done;
+                }
                 m_out = e.x;
                 b_out = e.y;
-                c_out = pk_max_i16(cin, cells.best);
-                if (tail) {
-                    if (tok & SWG_TOK_LAST) {
-                        const uint32_t pr = p.stream_pairs[pair0 + done];
-                        atomicMax(p.scores + 2u * pr, (int)(c_out & 0xFFFFu));
-                        atomicMax(p.scores + 2u * pr + 1u, (int)(c_out >> 16));
-                        ++done;
-                    }
-                    if (MULTIPASS) {
-                        const uint32_t row = s4 + (uint32_t)r - (uint32_t)(G - 1);
-                        if (pass + 1 < npass && row < rows) sp[row] = e; // row wraps negative -> huge
-                    }
+                if (MULTIPASS && tail) {
+                    const uint32_t row = s4 + (uint32_t)r - (uint32_t)(G - 1);
+                    if (pass + 1 < npass && row < rows) sp[row] = e; // row wraps negative -> huge
                 }
             }
             const uint32_t bi = s4 / 4u + 2u;
