@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--group", type=int, default=0, help="diagonal engine: lanes per sequence pair")
     ap.add_argument("--long-split", type=int, default=0, help="-1 off, 0 auto, else rows threshold of the long class")
     ap.add_argument("--long-cols", type=int, default=0, help="experiment: columns per lane of the long class")
+    ap.add_argument("--long-group", type=int, default=0, help="experiment: lanes per pair of the long class")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-len", type=int, default=0,
@@ -106,6 +107,7 @@ def main():
     ctx.set_option("group_lanes", args.group)
     ctx.set_option("long_split", args.long_split)
     ctx.set_option("long_cols", args.long_cols)
+    ctx.set_option("long_group", args.long_group)
     ctx.set_option("autotune", 0 if args.no_autotune else 1)
     db = swg.Database(flat, off).upload(ctx)
     residues = int(db.residues)

@@ -161,6 +161,9 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
     } else if (!strcmp(key, "long_cols")) {
         extern long g_swg_long_cols;
         g_swg_long_cols = value;
+    } else if (!strcmp(key, "long_group")) {
+        extern long g_swg_long_group;
+        g_swg_long_group = value;
     } else if (!strcmp(key, "autotune")) {
         ctx->opt_autotune = value != 0;
     } else if (!strcmp(key, "long_split")) {
@@ -524,7 +527,7 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
     }
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     double best_ms = 1e300;
-    for (const SwgDiagWork &c : pick) {
+    auto time_one = [&](const SwgDiagWork &c, double *ms_out) -> int {
         int rc = prepare_diag(ctx, db, c);
         if (rc != SWG_OK) return rc;
         double ms_min = 1e300;
@@ -538,10 +541,46 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
             if ((rc = diag_fill_ms(ctx, two, &ms)) != SWG_OK) return rc;
             ms_min = std::min(ms_min, ms);
         }
-        if (ms_min < best_ms) {
-            best_ms = ms_min;
+        *ms_out = ms_min;
+        return SWG_OK;
+    };
+    for (const SwgDiagWork &c : pick) {
+        double ms = 0;
+        int rc = time_one(c, &ms);
+        if (rc != SWG_OK) return rc;
+        if (ms < best_ms) {
+            best_ms = ms;
             *best = c;
-            best->plan[0].est_ms = ms_min;
+            best->plan[0].est_ms = ms;
+        }
+    }
+    // second stage: with the winning geometry, where to cut the long class off
+    if (best->n_classes == 2) {
+        const SwgDiagWork base = *best;
+        const uint64_t n_pairs = swg_db_pair_count(db);
+        const double mean_rows = (double)swg_db_pair_rows(db, 0, n_pairs, nullptr) / (double)base.plan[0].n_streams;
+        const double fractions[] = {0.25, 0.45, 0.8, 1.0, 1.3, 1.7};
+        for (double f : fractions) {
+            const long thr = (long)std::max(64.0, f * mean_rows);
+            std::vector<SwgDiagWork> alt;
+            if (swg_plan_diag_candidates(db, lq, ctx->n_cu, base.plan[0].K, base.plan[0].G, base.plan[0].W, thr, true,
+                                         &alt) <= 0)
+                continue;
+            const SwgDiagWork *same = nullptr;
+            for (const SwgDiagWork &c : alt)
+                if (c.n_classes == 2 && c.plan[1].K == base.plan[1].K && c.plan[1].G == base.plan[1].G) {
+                    same = &c;
+                    break;
+                }
+            if (!same || same->pair_end[1] == base.pair_end[1]) continue;
+            double ms = 0;
+            int rc = time_one(*same, &ms);
+            if (rc != SWG_OK) return rc;
+            if (ms < best_ms) {
+                best_ms = ms;
+                *best = *same;
+                best->plan[0].est_ms = ms;
+            }
         }
     }
     return SWG_OK;

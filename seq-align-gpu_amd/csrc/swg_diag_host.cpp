@@ -49,7 +49,8 @@ static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 18.0 : 
 
 // Long class: the cheapest geometry (instructions per pair-row, column padding included)
 // whose longest chain still finishes within `budget_cycles`; if none does, the shortest chain.
-long g_swg_long_cols = 0; // experiment switch: restrict the long class to this K (0 = free)
+long g_swg_long_cols = 0;  // experiment switch: restrict the long class to this K (0 = free)
+long g_swg_long_group = 0; // experiment switch: restrict the long class to this G (0 = free)
 
 static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_cycles, SwgDiagPlan *lp)
 {
@@ -66,6 +67,7 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
         if (g_swg_long_cols == 0 && info.K % 4 != 0) continue;
         for (int gi = 0; gi < 2; ++gi) {
             const int G = groups[gi];
+            if (g_swg_long_group > 0 && G != (int)g_swg_long_group) continue;
             const size_t cols = (size_t)G * info.K;
             if (cols * 64 > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
