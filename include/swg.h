@@ -154,6 +154,15 @@ const uint32_t *swg_db_order(const swg_db *db);
 int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out,
                swg_hit *topk_out, size_t k, size_t *n_hits, swg_stats *stats);
 
+/* The same search in two halves, so that a caller can keep the GPU busy: swg_search_begin queues
+ * everything on the context's stream and returns; swg_search_end waits for that search and
+ * delivers its results.  Up to 4 searches may be in flight per context (each has its own output
+ * buffers; they execute in order).  want_scores != 0 is required to get scores_out at the end.
+ * swg_search(...) == begin + end.  The database must stay alive and resident in between. */
+int swg_search_begin(swg_ctx *ctx, const swg_db *db, int want_scores, size_t k, int *ticket);
+int swg_search_end(swg_ctx *ctx, int ticket, int32_t *scores_out, swg_hit *topk_out, size_t *n_hits,
+                   swg_stats *stats);
+
 /* Reference-shaped replay of the call site itself: n_batches 16-lane batches
  * exactly as `alignment_fill_matrices` receives them -- db_idx_t is
  * aligner_t.seq_b_batch_indexes, [max_len][16] int8 (src/alignment.h:28,

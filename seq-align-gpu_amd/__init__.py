@@ -34,7 +34,8 @@ ABI_SYMBOLS = [
     "swg_create", "swg_destroy", "swg_last_error", "swg_global_error", "swg_abi_version",
     "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_upload",
     "swg_db_free", "swg_db_save", "swg_db_load", "swg_db_count", "swg_db_total_count", "swg_db_residues",
-    "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_fill_batches16", "swg_hit_key",
+    "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_search_begin", "swg_search_end",
+    "swg_fill_batches16", "swg_hit_key",
     "swg_key_hit", "swg_topk_merge_keys",
     "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
     "swg_scoring_load_matrix", "swg_query_sanitize", "swg_seqs_read", "swg_seqs_free",
@@ -117,6 +118,8 @@ _sig("swg_db_residues", C.c_uint64, [_vp])
 _sig("swg_db_packed_bytes", C.c_uint64, [_vp])
 _sig("swg_db_order", C.POINTER(C.c_uint32), [_vp])
 _sig("swg_search", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)])
+_sig("swg_search_begin", C.c_int, [_vp, _vp, C.c_int, C.c_size_t, C.POINTER(C.c_int)])
+_sig("swg_search_end", C.c_int, [_vp, C.c_int, _vp, _vp, C.POINTER(C.c_size_t), C.POINTER(Stats)])
 _sig("swg_fill_batches16", C.c_int, [_vp, C.POINTER(Batch16), C.c_size_t, C.POINTER(C.c_double)])
 _sig("swg_hit_key", C.c_uint64, [C.c_int32, C.c_uint32])
 _sig("swg_key_hit", None, [C.c_uint64, C.POINTER(Hit)])
@@ -329,6 +332,51 @@ class Context:
                             C.cast(hits, _vp) if k else None, k, C.byref(nh), C.byref(st))
         _check(rc, self.handle)
         return scores, [(int(hits[i].score), int(hits[i].index)) for i in range(nh.value)], st.as_dict()
+
+    def search_begin(self, db, k=0, want_scores=False):
+        """Queue a search; returns a ticket for search_end / search_end_keys."""
+        t = C.c_int(-1)
+        _check(lib.swg_search_begin(self.handle, db.handle, 1 if want_scores else 0, k, C.byref(t)), self.handle)
+        return (t.value, db, k, want_scores)
+
+    def search_end(self, ticket):
+        t, db, k, want_scores = ticket
+        scores = np.zeros(db.total_count, dtype=np.int32) if want_scores else None
+        hits = (Hit * max(k, 1))()
+        nh = C.c_size_t(0)
+        st = Stats()
+        _check(lib.swg_search_end(self.handle, t, scores.ctypes.data_as(_vp) if want_scores else None,
+                                  C.cast(hits, _vp) if k else None, C.byref(nh), C.byref(st)), self.handle)
+        return scores, [(int(hits[i].score), int(hits[i].index)) for i in range(nh.value)], st.as_dict()
+
+    def search_end_keys(self, ticket):
+        """As search_keys, for a search queued with search_begin."""
+        t, db, k, _ = ticket
+        hits = (Hit * max(k, 1))()
+        nh = C.c_size_t(0)
+        st = Stats()
+        _check(lib.swg_search_end(self.handle, t, None, C.cast(hits, _vp), C.byref(nh), C.byref(st)), self.handle)
+        return self._hit_keys(hits, k, nh.value), st.as_dict()
+
+    @staticmethod
+    def _hit_keys(hits, k, n):
+        a = np.frombuffer(hits, dtype=np.dtype([("score", "<i4"), ("index", "<u4")]), count=max(k, 1))[:k]
+        keys = (a["score"].astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - a["index"].astype(np.uint64))
+        keys[n:] = 0
+        return keys
+
+    def search_keys(self, db, k):
+        """Top-K of this shard as uint64 sort keys (score << 32 | ~index), zero-padded to k, plus
+        stats: the form the multi-GPU merge exchanges (no per-hit Python objects)."""
+        hits = (Hit * max(k, 1))()
+        nh = C.c_size_t(0)
+        st = Stats()
+        _check(lib.swg_search(self.handle, db.handle, None, C.cast(hits, _vp), k, C.byref(nh), C.byref(st)),
+               self.handle)
+        a = np.frombuffer(hits, dtype=np.dtype([("score", "<i4"), ("index", "<u4")]), count=max(k, 1))[:k]
+        keys = (a["score"].astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - a["index"].astype(np.uint64))
+        keys[nh.value:] = 0
+        return keys, st.as_dict()
 
     def fill_batches16(self, batches):
         """batches: list of (db_idx_t int8[max_len,16], vector_size) -> list of int16[vector_size]."""

@@ -57,10 +57,10 @@ int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
 // milliseconds per search, several times the fill itself.
 static hipError_t spin_sync(swg_ctx *ctx, hipStream_t s)
 {
-    hipError_t e = hipEventRecord(ctx->ev_done, s);
+    hipError_t e = hipEventRecord(ctx->cur->ev_done, s);
     if (e != hipSuccess) return e;
     for (;;) {
-        e = hipEventQuery(ctx->ev_done);
+        e = hipEventQuery(ctx->cur->ev_done);
         if (e != hipErrorNotReady) return e;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -106,8 +106,13 @@ extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
             HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
         }
-        for (auto &ev : ctx->ev) HIP_TRY(ctx, hipEventCreate(&ev));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
+        for (SwgSlot &sl : ctx->slots) {
+            for (auto &ev : sl.ev) HIP_TRY(ctx, hipEventCreate(&ev));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_cand), SWG_TOPK_CAND_CAP * 8, hipHostMallocDefault));
+            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_counters), 64, hipHostMallocDefault));
+        }
+        ctx->cur = &ctx->slots[0];
         HIP_TRY(ctx, hipMalloc(&ctx->d_sub, 32 * 32));
         return SWG_OK;
     }();
@@ -131,9 +136,13 @@ extern "C" void swg_destroy(swg_ctx *ctx)
     (void)hipFree(ctx->d_profile[1]);
     (void)hipFree(ctx->d_profile[2]);
     (void)hipFree(ctx->d_scratch);
-    for (auto &ev : ctx->ev)
-        if (ev) (void)hipEventDestroy(ev);
-    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+    for (SwgSlot &sl : ctx->slots) {
+        for (auto &ev : sl.ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        (void)hipHostFree(sl.h_cand);
+        (void)hipHostFree(sl.h_counters);
+    }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -230,12 +239,14 @@ void swg_db_release_device(swg_db *db)
     (void)hipFree(db->d_bin_off);
     (void)hipFree(db->d_bin_nblk);
     (void)hipFree(db->d_order);
-    (void)hipFree(db->d_scores);
-    (void)hipFree(db->d_list);
-    (void)hipFree(db->d_counters);
-    (void)hipFree(db->d_keys);
-    (void)hipFree(db->d_hist);
-    db->d_hist = nullptr;
+    for (swg_db::Bufs &b : db->bufs) {
+        (void)hipFree(b.d_scores);
+        (void)hipFree(b.d_list);
+        (void)hipFree(b.d_counters);
+        (void)hipFree(b.d_keys);
+        (void)hipFree(b.d_hist);
+        b = swg_db::Bufs();
+    }
     for (SwgDiagLayout &L : db->diag) {
         (void)hipFree(L.d_tok);
         (void)hipFree(L.d_stream_off);
@@ -252,7 +263,28 @@ void swg_db_release_device(swg_db *db)
     db->d_list = nullptr;
     db->d_counters = nullptr;
     db->d_keys = nullptr;
+    db->d_hist = nullptr;
     db->device = -1;
+}
+
+// Output buffers of in-flight slot `slot` (allocated on first use) become the current ones.
+static int select_bufs(swg_ctx *ctx, swg_db *db, int slot)
+{
+    swg_db::Bufs &b = db->bufs[slot];
+    const size_t ns = (size_t)db->n_bins * SWG_BIN;
+    if (!b.d_scores) {
+        HIP_TRY(ctx, hipMalloc(&b.d_scores, std::max<size_t>(4, ns * 4)));
+        HIP_TRY(ctx, hipMalloc(&b.d_list, std::max<size_t>(4, ns * 4)));
+        HIP_TRY(ctx, hipMalloc(&b.d_counters, 64));
+        HIP_TRY(ctx, hipMalloc(&b.d_keys, SWG_TOPK_CAND_CAP * 8));
+        HIP_TRY(ctx, hipMalloc(&b.d_hist, 4096 * 4));
+    }
+    db->d_scores = b.d_scores;
+    db->d_list = b.d_list;
+    db->d_counters = b.d_counters;
+    db->d_keys = b.d_keys;
+    db->d_hist = b.d_hist;
+    return SWG_OK;
 }
 
 extern "C" int swg_db_upload(swg_ctx *ctx, swg_db *db)
@@ -267,11 +299,8 @@ extern "C" int swg_db_upload(swg_ctx *ctx, swg_db *db)
         HIP_TRY(ctx, hipMalloc(&db->d_bin_off, std::max<size_t>(8, nb * 8)));
         HIP_TRY(ctx, hipMalloc(&db->d_bin_nblk, std::max<size_t>(4, nb * 4)));
         HIP_TRY(ctx, hipMalloc(&db->d_order, std::max<size_t>(4, ns * 4)));
-        HIP_TRY(ctx, hipMalloc(&db->d_scores, std::max<size_t>(4, ns * 4)));
-        HIP_TRY(ctx, hipMalloc(&db->d_list, std::max<size_t>(4, ns * 4)));
-        HIP_TRY(ctx, hipMalloc(&db->d_counters, 64));
-        HIP_TRY(ctx, hipMalloc(&db->d_keys, SWG_TOPK_CAND_CAP * 8));
-        HIP_TRY(ctx, hipMalloc(&db->d_hist, 4096 * 4));
+        int rb = select_bufs(ctx, db, 0);
+        if (rb != SWG_OK) return rb;
         if (nb) {
             HIP_TRY(ctx, hipMemcpyAsync(db->d_packed, db->packed.data(), db->packed.size() * 4,
                                         hipMemcpyHostToDevice, ctx->stream));
@@ -449,11 +478,11 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
     hipStream_t s = ctx->stream;
     const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
     *two_ends = false;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
     if (wk.n_classes == 2) {
         // fork: the long pairs start first, on their own stream, beside the bulk
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[6], s));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[6], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->cur->ev[6], 0));
     }
     for (int c = wk.n_classes - 1; c >= 0; --c) {
         const SwgDiagLayout &L = db->diag[c];
@@ -484,24 +513,24 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
     }
     if (wk.n_classes == 2) {
         // join; the end of the fill is the later of the two kernels' ends
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[7], ctx->stream2));
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[7], 0));
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[5], s));
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[7], ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->cur->ev[7], 0));
         *two_ends = true;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
     return SWG_OK;
 }
 
 static int diag_fill_ms(swg_ctx *ctx, bool two_ends, double *out)
 {
     float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[1], ctx->cur->ev[2]));
     *out = ms;
     if (two_ends) {
         float a = 0.f, b = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[5]));
-        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[7]));
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->cur->ev[1], ctx->cur->ev[5]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->cur->ev[1], ctx->cur->ev[7]));
         *out = std::max(*out, (double)std::max(a, b));
     }
     return SWG_OK;
@@ -612,29 +641,37 @@ extern "C" size_t swg_topk_merge_keys(const uint64_t *keys, size_t n, size_t k, 
     return m;
 }
 
-extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, swg_hit *topk_out,
-                          size_t k, size_t *n_hits, swg_stats *stats)
+// Queues one whole search on the context's stream and returns without waiting (except on the
+// first search of a query length, which tunes the geometry, and when int16 scores may
+// saturate, where the number of flagged sequences is read back to size the re-score).
+static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t k, SwgSlot *S)
 {
     if (!ctx || !db) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search: NULL argument");
     if (!ctx->have_scoring) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: no scoring set");
     if (ctx->query.empty()) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: no query set");
-    if (db->device != ctx->device || !db->d_scores)
+    if (db->device != ctx->device || !db->d_packed)
         return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: database is not resident on device %d",
                                  ctx->device);
-    if (k > 0 && !topk_out) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search: k > 0 but topk_out NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (n_hits) *n_hits = 0;
-    swg_stats st;
+    ctx->cur = S;
+    {
+        const int rb = select_bufs(ctx, const_cast<swg_db *>(db), (int)(S - ctx->slots));
+        if (rb != SWG_OK) return rb;
+    }
+    S->bufs = db->bufs[S - ctx->slots];
+    S->db = db;
+    S->k = k;
+    S->want_scores = want_scores;
+    S->h_scores.clear();
+    swg_stats &st = S->st;
     memset(&st, 0, sizeof st);
     const size_t lq = ctx->query.size();
     const uint32_t n_bins = db->n_bins;
     const size_t n_slots = (size_t)n_bins * SWG_BIN;
     st.cells = (uint64_t)lq * db->residues;
     st.bytes_alg = db->residues + 8ull * db->n_local + 32ull * lq + 1024ull;
-    if (n_bins == 0) {
-        if (stats) *stats = st;
-        return SWG_OK;
-    }
+    S->bits = 0; // marks "nothing queued" for an empty database
+    if (n_bins == 0) return SWG_OK;
 
     // which arithmetic: the packed int16 form needs non-positive gap scores
     const int go = ctx->gap_open + ctx->gap_extend, ge = ctx->gap_extend;
@@ -646,6 +683,8 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
                                  "force_bits=16 needs gap_open <= 0 and gap_extend <= 0");
 
     Plan main_pl, re_pl;
+    memset(&main_pl, 0, sizeof main_pl);
+    memset(&re_pl, 0, sizeof re_pl);
     int rc = make_plan(ctx, bits, bits == 16 ? n_bins : n_bins * 2, &main_pl);
     if (rc != SWG_OK && !(bits == 16 && ctx->opt_engine != 1)) return rc;
     // int16: the diagonal engine unless the systolic one is asked for
@@ -719,7 +758,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     }
 
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[0], s));
     HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, s));
     HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, 64, s));
 
@@ -733,7 +772,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     p.scratch = ctx->d_scratch;
 
     bool two_ends = false;
-    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
     if (use_diag) {
         if ((rc = launch_diag(ctx, db, wk, go, ge, &two_ends)) != SWG_OK) return rc;
     } else if (bits == 32 && use_diag32) {
@@ -765,7 +804,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb;
         HIP_TRY(ctx, swg_launch_fill(bits, main_pl.variant, main_pl.W, main_pl.workgroups, p, s));
     }
-    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
     if (may_saturate) {
         HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, db->d_list,
                                                   db->d_counters + 1, s));
@@ -796,51 +835,90 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
             HIP_TRY(ctx, swg_launch_fill(32, re_pl.variant, re_pl.W, re_pl.workgroups, p, s));
         }
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[3], s));
 
     // top-K on the device unless every score goes to the host anyway
-    const bool dev_topk = k > 0 && scores_out == nullptr && k <= SWG_TOPK_CAND_CAP / 2;
+    const bool dev_topk = k > 0 && !want_scores && k <= SWG_TOPK_CAND_CAP / 2;
     if (dev_topk)
         HIP_TRY(ctx, swg_launch_topk(db->d_scores, db->d_order, (uint32_t)n_slots, (uint32_t)k, db->d_hist,
                                      db->d_counters + 4, db->d_keys, SWG_TOPK_CAND_CAP, db->d_counters + 3, s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[4], s));
 
-    // read-out
-    std::vector<int32_t> h_scores;
-    std::vector<uint64_t> h_cand;
-    uint32_t h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool need_scores = scores_out != nullptr || (k > 0 && !dev_topk);
-    const size_t first_chunk = std::min<size_t>(SWG_TOPK_CAND_CAP, 2 * k + 64);
-    if (dev_topk) {
-        h_cand.resize(SWG_TOPK_CAND_CAP);
-        HIP_TRY(ctx, hipMemcpyAsync(h_cand.data(), db->d_keys, first_chunk * 8, hipMemcpyDeviceToHost, s));
+    // read-out, queued behind the kernels; swg_search_end waits for it
+    S->bits = bits;
+    S->dev_topk = dev_topk;
+    S->need_scores = want_scores || (k > 0 && !dev_topk);
+    S->first_chunk = SWG_TOPK_CAND_CAP;
+    S->two_ends = two_ends;
+    S->may_saturate = may_saturate;
+    S->use_diag = use_diag;
+    S->use_diag32 = use_diag32;
+    S->npass32 = npass32;
+    S->wk = wk;
+    S->main_K = main_pl.K;
+    S->main_W = main_pl.W;
+    S->main_npass = main_pl.npass;
+    S->main_wgs = main_pl.workgroups;
+    if (dev_topk)
+        HIP_TRY(ctx, hipMemcpyAsync(S->h_cand, db->d_keys, S->first_chunk * 8, hipMemcpyDeviceToHost, s));
+    if (S->need_scores) {
+        S->h_scores.resize(n_slots);
+        HIP_TRY(ctx, hipMemcpyAsync(S->h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
     }
-    if (need_scores) {
-        h_scores.resize(n_slots);
-        HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_counters, db->d_counters, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(S->ev_done, s));
+    return SWG_OK;
+}
+
+static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *topk_out, size_t *n_hits,
+                      swg_stats *stats)
+{
+    const swg_db *db = S->db;
+    const size_t k = S->k;
+    if (n_hits) *n_hits = 0;
+    if (k > 0 && !topk_out) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search: k > 0 but topk_out NULL");
+    if (scores_out && !S->want_scores)
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_end: scores were not requested at swg_search_begin");
+    swg_stats &st = S->st;
+    if (S->bits == 0) { // empty database
+        if (stats) *stats = st;
+        return SWG_OK;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(h_counters, db->d_counters, sizeof h_counters, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, spin_sync(ctx, s));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->cur = S;
+    hipStream_t s = ctx->stream;
+    for (;;) { // poll: a blocking wait can cost milliseconds of wake-up latency on a busy host
+        const hipError_t q = hipEventQuery(S->ev_done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(ctx, q);
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
+    const bool dev_topk = S->dev_topk, two_ends = S->two_ends, may_saturate = S->may_saturate;
+    const bool use_diag = S->use_diag, use_diag32 = S->use_diag32;
+    const int bits = S->bits, npass32 = S->npass32;
+    const SwgDiagWork &wk = S->wk;
+    const SwgDiagPlan &dpl = wk.plan[0];
+    uint32_t *h_counters = S->h_counters;
+    uint64_t *h_cand = S->h_cand;
+    std::vector<int32_t> &h_scores = S->h_scores;
+    int rc = SWG_OK;
     bool cand_ok = dev_topk && h_counters[5] == 0 && h_counters[3] <= SWG_TOPK_CAND_CAP;
-    if (cand_ok && h_counters[3] > first_chunk) {
-        HIP_TRY(ctx, hipMemcpyAsync(h_cand.data() + first_chunk, db->d_keys + first_chunk,
-                                    (h_counters[3] - first_chunk) * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, spin_sync(ctx, s));
-    }
     if (dev_topk && !cand_ok) { // threshold beyond the histogram or too many ties: select on the host
         h_scores.resize(n_slots);
-        HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), S->bufs.d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, spin_sync(ctx, s));
-        need_scores = true;
     }
 
     float ms = 0.f;
     if ((rc = diag_fill_ms(ctx, two_ends, &st.fill_ms)) != SWG_OK) return rc;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[2], ctx->cur->ev[3]));
     st.rescore_ms = may_saturate ? ms : 0.0;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[0], ctx->cur->ev[4]));
     st.total_ms = ms;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[3], ctx->cur->ev[4]));
     const double topk_dev_ms = ms;
     st.n_rescored = h_counters[1];
     st.path_bits = bits;
@@ -870,11 +948,11 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
         st.cells_padded = (uint64_t)npass32 * 64 * SWG_DIAG32_K * ((uint64_t)db->rows_padded);
     } else {
         st.engine = 1;
-        st.cols_per_wave = main_pl.K;
-        st.waves = main_pl.W;
-        st.passes = main_pl.npass;
-        st.workgroups = main_pl.workgroups;
-        st.cells_padded = (uint64_t)main_pl.npass * main_pl.W * main_pl.K * db->rows_padded;
+        st.cols_per_wave = S->main_K;
+        st.waves = S->main_W;
+        st.passes = S->main_npass;
+        st.workgroups = S->main_wgs;
+        st.cells_padded = (uint64_t)S->main_npass * S->main_W * S->main_K * db->rows_padded;
     }
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -887,7 +965,7 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     if (k > 0) {
         std::vector<uint64_t> keys;
         if (cand_ok) {
-            keys.assign(h_cand.begin(), h_cand.begin() + h_counters[3]);
+            keys.assign(h_cand, h_cand + h_counters[3]);
         } else {
             keys.reserve(db->n_local);
             for (size_t i = 0; i < n_slots; ++i) {
@@ -903,6 +981,47 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
     st.topk_ms = topk_dev_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (stats) *stats = st;
     return SWG_OK;
+}
+
+extern "C" int swg_search_begin(swg_ctx *ctx, const swg_db *db, int want_scores, size_t k, int *ticket)
+{
+    if (!ctx || !db || !ticket) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_begin: NULL argument");
+    int slot = -1;
+    for (int i = 0; i < SWG_MAX_INFLIGHT; ++i) {
+        const int c = (ctx->next_slot + i) % SWG_MAX_INFLIGHT;
+        if (!ctx->slots[c].busy) {
+            slot = c;
+            break;
+        }
+    }
+    if (slot < 0)
+        return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_begin: %d searches already in flight", SWG_MAX_INFLIGHT);
+    const int rc = search_begin(ctx, db, want_scores != 0, k, &ctx->slots[slot]);
+    if (rc != SWG_OK) return rc;
+    ctx->slots[slot].busy = true;
+    ctx->next_slot = (slot + 1) % SWG_MAX_INFLIGHT;
+    *ticket = slot;
+    return SWG_OK;
+}
+
+extern "C" int swg_search_end(swg_ctx *ctx, int ticket, int32_t *scores_out, swg_hit *topk_out, size_t *n_hits,
+                              swg_stats *stats)
+{
+    if (!ctx || ticket < 0 || ticket >= SWG_MAX_INFLIGHT || !ctx->slots[ticket].busy)
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_end: no search in flight under that ticket");
+    const int rc = search_end(ctx, &ctx->slots[ticket], scores_out, topk_out, n_hits, stats);
+    ctx->slots[ticket].busy = false;
+    return rc;
+}
+
+extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, swg_hit *topk_out, size_t k,
+                          size_t *n_hits, swg_stats *stats)
+{
+    if (k > 0 && !topk_out) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search: k > 0 but topk_out NULL");
+    int ticket = -1;
+    const int rc = swg_search_begin(ctx, db, scores_out != nullptr, k, &ticket);
+    if (rc != SWG_OK) return rc;
+    return swg_search_end(ctx, ticket, scores_out, topk_out, n_hits, stats);
 }
 
 // ---------------------------------------------------------------------------

@@ -69,11 +69,41 @@ struct swg_db {
     uint64_t *d_bin_off = nullptr;
     uint32_t *d_bin_nblk = nullptr;
     uint32_t *d_order = nullptr;
-    int32_t *d_scores = nullptr;  // [n_bins*128]
-    uint32_t *d_list = nullptr;   // [n_bins*128] saturated slot ids
-    uint32_t *d_counters = nullptr; // [0] work queue, [1] saturated count, [2] queue of rescore
-    uint64_t *d_keys = nullptr;   // top-K candidate keys (SWG_TOPK_CAND_CAP)
-    uint32_t *d_hist = nullptr;   // top-K score histogram
+    // per-search output buffers, one set per in-flight slot (allocated on first use); the
+    // plain members below point at the set of the search being queued
+    struct Bufs {
+        int32_t *d_scores = nullptr;    // [n_bins*128] by sorted rank
+        uint32_t *d_list = nullptr;     // [n_bins*128] saturated ranks
+        uint32_t *d_counters = nullptr; // [0] work queue, [1] saturated count, [2] re-score queue, [3..5] top-K
+        uint64_t *d_keys = nullptr;     // top-K candidate keys (SWG_TOPK_CAND_CAP)
+        uint32_t *d_hist = nullptr;     // top-K score histogram
+    } bufs[4];
+    int32_t *d_scores = nullptr;
+    uint32_t *d_list = nullptr;
+    uint32_t *d_counters = nullptr;
+    uint64_t *d_keys = nullptr;
+    uint32_t *d_hist = nullptr;
+};
+
+// One search in flight: its timing events, host-side landing buffers and what swg_search_end
+// needs to finish it.  Device buffers are shared: everything of one context runs in stream
+// order, so search i+1 cannot touch them before search i has copied its results out.
+#define SWG_MAX_INFLIGHT 4
+struct SwgSlot {
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_done = nullptr; // polled from user space instead of a blocking stream sync
+    bool busy = false;
+    const swg_db *db = nullptr;
+    swg_db::Bufs bufs; // the output buffers this search writes
+    size_t k = 0, first_chunk = 0;
+    bool want_scores = false, dev_topk = false, need_scores = false, two_ends = false, may_saturate = false;
+    bool use_diag = false, use_diag32 = false;
+    int bits = 0, npass32 = 0, main_K = 0, main_W = 0, main_npass = 0, main_wgs = 0;
+    SwgDiagWork wk;
+    swg_stats st;
+    uint64_t *h_cand = nullptr;     // pinned, SWG_TOPK_CAND_CAP keys
+    uint32_t *h_counters = nullptr; // pinned, 8 words
+    std::vector<int32_t> h_scores;
 };
 
 struct swg_ctx {
@@ -100,8 +130,9 @@ struct swg_ctx {
     uint64_t epoch = 1;               // bumps whenever scoring or query change
     uint32_t *d_scratch = nullptr;
     size_t d_scratch_cap = 0; // dwords
-    hipEvent_t ev_done = nullptr; // polled from user space instead of a blocking stream sync
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SwgSlot slots[SWG_MAX_INFLIGHT];
+    SwgSlot *cur = nullptr; // slot whose events the launch helpers record into
+    int next_slot = 0;
 };
 
 int swg_set_global_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

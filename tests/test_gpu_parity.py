@@ -263,6 +263,36 @@ def test_device_topk_matches_oracle_order(swg, ctx, orc, name):
     db.close()
 
 
+def test_searches_in_flight(swg, ctx, orc):
+    """swg_search_begin/end: four searches queued back to back (two databases, full scores and
+    device top-K mixed) each deliver their own results; a fifth begin is refused."""
+    g1, g2 = load_golden("blosum62_lq367"), load_golden("pam250_partial_lanes")
+    _setup(ctx, g1)
+    db1 = swg.Database(g1["flat"], g1["offsets"]).upload(ctx)
+    # same scoring/query for everything in flight; second database scored against g1's query
+    db2 = swg.Database(g2["flat"], g2["offsets"]).upload(ctx)
+    want2 = orc.score_db(g1["query"], g2["flat"], g2["offsets"], g1["sub"], -2, -1)
+    t = [ctx.search_begin(db1, k=10), ctx.search_begin(db2, k=0, want_scores=True),
+         ctx.search_begin(db1, k=5, want_scores=True), ctx.search_begin(db2, k=50)]
+    with pytest.raises(swg.SwgError) as e:
+        ctx.search_begin(db1, k=1)
+    assert e.value.code == swg.SWG_ERR_STATE
+    s3, h3, _ = ctx.search_end(t[2])          # out of order on purpose
+    s1, h1, _ = ctx.search_end(t[0])
+    s2, h2, _ = ctx.search_end(t[1])
+    keys4, _ = ctx.search_end_keys(t[3])
+    assert s1 is None and h1 == orc.topk(g1["oracle32"], 10)
+    assert np.array_equal(s2, want2) and h2 == []
+    assert np.array_equal(s3, g1["oracle32"]) and h3 == orc.topk(g1["oracle32"], 5)
+    assert swg.topk_merge_keys(keys4, 50) == orc.topk(want2, 50)
+    with pytest.raises(swg.SwgError):
+        ctx.search_end(t[0])                  # ticket already redeemed
+    again, _, _ = ctx.search(db1)             # slots are free again
+    assert np.array_equal(again, g1["oracle32"])
+    db1.close()
+    db2.close()
+
+
 def test_errors_are_codes_not_crashes(swg, ctx):
     g = load_golden("blosum62_lq1")
     _setup(ctx, g)
