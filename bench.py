@@ -112,6 +112,9 @@ def main():
     ctx.set_option("autotune", 0 if args.no_autotune else 1)
     db = swg.Database(flat, off).upload(ctx)
     residues = int(db.residues)
+    # setup, untimed like the upload: the first search of a query length plans and autotunes the
+    # kernel geometry for this database on this device
+    ctx.search(db, want_scores=False, k=args.topk)
 
     K = args.topk
     merger = TopKMerger(swg, K, rank, world, "cuda") if use_dist else None
