@@ -189,6 +189,27 @@ void swg_key_hit(uint64_t key, swg_hit *out);
 /* keys[n] (zeros ignored) -> best k hits, sorted.  Returns hits written. */
 size_t swg_topk_merge_keys(const uint64_t *keys, size_t n, size_t k, swg_hit *out);
 
+/* ---- several GPUs in one process ----------------------------------------- */
+
+/* A group owns one context per device.  swg_group_load deals the database's bins round-robin
+ * over the devices; swg_group_search runs all shards concurrently and merges their top-K lists
+ * with a single RCCL max-all-reduce of n_gpus*k hit keys (RCCL is loaded on first use; with one
+ * device no collective is issued unless force_collective is set, which is how a 1-GPU box
+ * rehearses the path).  scores_out is indexed by original database index; stats, if given, is
+ * an array of swg_group_size() entries.  (bench.py uses the other arrangement: one process per
+ * GPU, torch.distributed over RCCL.) */
+typedef struct swg_group swg_group;
+int swg_group_create(const int *devices /* NULL: 0..n-1 */, int n, int force_collective, swg_group **out);
+void swg_group_destroy(swg_group *g);
+int swg_group_size(const swg_group *g);
+const char *swg_group_last_error(const swg_group *g);
+int swg_group_set_option(swg_group *g, const char *key, long value);
+int swg_group_set_scoring(swg_group *g, const int8_t sub[32][32], int gap_open, int gap_extend);
+int swg_group_set_query(swg_group *g, const int8_t *idx, size_t lq);
+int swg_group_load(swg_group *g, const int8_t *flat, const uint64_t *offsets, size_t n);
+int swg_group_search(swg_group *g, int32_t *scores_out, swg_hit *topk_out, size_t k, size_t *n_hits,
+                     swg_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

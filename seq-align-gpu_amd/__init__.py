@@ -37,6 +37,8 @@ ABI_SYMBOLS = [
     "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_search_begin", "swg_search_end",
     "swg_fill_batches16", "swg_hit_key",
     "swg_key_hit", "swg_topk_merge_keys",
+    "swg_group_create", "swg_group_destroy", "swg_group_size", "swg_group_last_error", "swg_group_set_option",
+    "swg_group_set_scoring", "swg_group_set_query", "swg_group_load", "swg_group_search",
     "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
     "swg_scoring_load_matrix", "swg_query_sanitize", "swg_seqs_read", "swg_seqs_free",
     "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar",
@@ -124,6 +126,15 @@ _sig("swg_fill_batches16", C.c_int, [_vp, C.POINTER(Batch16), C.c_size_t, C.POIN
 _sig("swg_hit_key", C.c_uint64, [C.c_int32, C.c_uint32])
 _sig("swg_key_hit", None, [C.c_uint64, C.POINTER(Hit)])
 _sig("swg_topk_merge_keys", C.c_size_t, [_vp, C.c_size_t, C.c_size_t, _vp])
+_sig("swg_group_create", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)])
+_sig("swg_group_destroy", None, [_vp])
+_sig("swg_group_size", C.c_int, [_vp])
+_sig("swg_group_last_error", C.c_char_p, [_vp])
+_sig("swg_group_set_option", C.c_int, [_vp, C.c_char_p, C.c_long])
+_sig("swg_group_set_scoring", C.c_int, [_vp, _vp, C.c_int, C.c_int])
+_sig("swg_group_set_query", C.c_int, [_vp, _vp, C.c_size_t])
+_sig("swg_group_load", C.c_int, [_vp, _vp, _vp, C.c_size_t])
+_sig("swg_group_search", C.c_int, [_vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)])
 _sig("swg_letter_index", C.c_int, [C.c_int])
 _sig("swg_index_letter", C.c_int, [C.c_int])
 _sig("swg_scoring_init", None, [C.POINTER(Scoring)])
@@ -398,6 +409,58 @@ class Context:
     def close(self):
         if self.handle:
             lib.swg_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+class Group:
+    """swg_group: several GPUs in one process, shards merged with one RCCL all-reduce."""
+
+    def __init__(self, devices, force_collective=False):
+        self.handle = None
+        devs = (C.c_int * len(devices))(*devices)
+        h = _vp()
+        _check(lib.swg_group_create(C.cast(devs, _vp), len(devices), 1 if force_collective else 0, C.byref(h)))
+        self.handle = h
+        self.n = len(devices)
+        self.total = 0
+
+    def _chk(self, rc):
+        if rc != SWG_OK:
+            raise SwgError(rc, (lib.swg_group_last_error(self.handle) or b"").decode("utf-8", "replace"))
+
+    def set_option(self, key, value):
+        self._chk(lib.swg_group_set_option(self.handle, key.encode(), int(value)))
+
+    def set_scoring(self, sub, gap_open, gap_extend):
+        if isinstance(sub, Scoring):
+            sub = sub.table()
+        s, sp = _i8(np.asarray(sub).reshape(32, 32))
+        self._chk(lib.swg_group_set_scoring(self.handle, sp, int(gap_open), int(gap_extend)))
+
+    def set_query(self, idx):
+        q, qp = _i8(idx)
+        self._chk(lib.swg_group_set_query(self.handle, qp, q.size))
+
+    def load(self, flat, offsets):
+        f, fp = _i8(flat)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._chk(lib.swg_group_load(self.handle, fp, o.ctypes.data_as(_vp), o.size - 1))
+        self.total = o.size - 1
+
+    def search(self, want_scores=True, k=0):
+        scores = np.zeros(self.total, dtype=np.int32) if want_scores else None
+        hits = (Hit * max(k, 1))()
+        nh = C.c_size_t(0)
+        st = (Stats * self.n)()
+        self._chk(lib.swg_group_search(self.handle, scores.ctypes.data_as(_vp) if want_scores else None,
+                                       C.cast(hits, _vp) if k else None, k, C.byref(nh), st))
+        return scores, [(int(hits[i].score), int(hits[i].index)) for i in range(nh.value)], [s.as_dict() for s in st]
+
+    def close(self):
+        if self.handle:
+            lib.swg_group_destroy(self.handle)
             self.handle = None
 
     __del__ = close

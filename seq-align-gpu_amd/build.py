@@ -29,7 +29,7 @@ ARCH = "gfx950"
 # (The host half of the compile prints a harmless "not a recognized feature".)
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 
-HIP_SOURCES = ["swg_kernels.hip", "swg_api.cpp"]
+HIP_SOURCES = ["swg_kernels.hip", "swg_api.cpp", "swg_group.cpp"]
 CXX_SOURCES = ["swg_pack.cpp", "swg_diag_host.cpp"]  # host-only C++, OpenMP via g++
 C_SOURCES = ["swg_scoring.c", "swg_seqio.c", "swg_synth.c"]
 CLI_SOURCES = ["sw_cmdline.c"]
@@ -95,7 +95,7 @@ def build(force=False, verbose=True):
         if verbose:
             print("[link] libswg.so")
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
-             + ["-lgomp", "-lz", "-lm"])
+             + ["-lgomp", "-lz", "-lm", "-ldl"])
     cli_srcs = [os.path.join(HOST, s) for s in CLI_SOURCES if os.path.exists(os.path.join(HOST, s))]
     if cli_srcs and (force or _stale(CLI, cli_srcs + [LIB] + hdrs)):
         if verbose:

@@ -10,7 +10,8 @@
  *   - "Entry #n" is always the true 0-based record index (A.7-3);
  *   - the substitution matrix is mandatory and undefined pairs score 0 (A.7-1,2);
  *   - scores above 32767 are exact instead of wrapped (A.4);
- *   - --topk K appends a ranked report; --gpu N selects the device.
+ *   - --topk K appends a ranked report; --gpu N selects the device; --gpus N shards the
+ *     database over devices 0..N-1 (one RCCL all-reduce merges the top-K lists).
  * There is no CPU backend: without a GPU the tool fails with a message.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -40,7 +41,8 @@ static void usage(const char *argv0, const char *err)
             "    --printfasta         print record names\n"
             "    --printmatrices --pretty --colour --scoring <x>   accepted, no effect\n"
             "    --topk <K>           append the K best hits (score, index, name)\n"
-            "    --gpu <N>            HIP device ordinal [default: 0]\n",
+            "    --gpu <N>            HIP device ordinal [default: 0]\n"
+            "    --gpus <N>           shard the database over GPUs 0..N-1 (RCCL top-K merge)\n",
             argv0);
     exit(EXIT_FAILURE);
 }
@@ -67,7 +69,7 @@ int main(int argc, char **argv)
     swg_scoring_init(&sc);
     const char *qpath = NULL, *dbpath = NULL;
     int print_seq = 0, print_fasta = 0, have_matrix = 0;
-    long topk = 0, gpu = 0, v;
+    long topk = 0, gpu = 0, gpus = 0, v;
     if (argc == 1) usage(argv[0], NULL);
     for (int i = 1; i < argc; i++)
         if (!strcasecmp(argv[i], "--help") || !strcasecmp(argv[i], "-help") || !strcasecmp(argv[i], "-h"))
@@ -102,6 +104,9 @@ int main(int argc, char **argv)
             i++;
         } else if (!strcasecmp(a, "--topk")) {
             if (!parse_int(argv[i + 1], 0, 1 << 20, &topk)) usage(argv[0], "Invalid --topk argument");
+            i++;
+        } else if (!strcasecmp(a, "--gpus")) {
+            if (!parse_int(argv[i + 1], 1, 64, &gpus)) usage(argv[0], "Invalid --gpus argument");
             i++;
         } else if (!strcasecmp(a, "--gpu")) {
             if (!parse_int(argv[i + 1], 0, 1023, &gpu)) usage(argv[0], "Invalid --gpu argument");
@@ -152,31 +157,55 @@ int main(int argc, char **argv)
     swg_query_sanitize(&sc, qidx, lq); /* reference src/alignment_cmdline.c:391-396 */
     if (swg_seqs_to_indices(&db, didx, &bad) != SWG_OK) die_illegal(bad);
 
-    swg_ctx *ctx = NULL;
-    swg_config cfg;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.device = (int)gpu;
-    if (swg_create(&cfg, &ctx) != SWG_OK) {
-        fprintf(stderr, "Error: %s\n", swg_global_error());
-        return EXIT_FAILURE;
-    }
-    swg_db *pdb = NULL;
     int32_t *scores = (int32_t *)calloc(db.n ? db.n : 1, sizeof(int32_t));
     swg_hit *hits = (swg_hit *)calloc(topk ? (size_t)topk : 1, sizeof(swg_hit));
     size_t n_hits = 0;
-    swg_stats st;
-    memset(&st, 0, sizeof st);
-    int rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
-    if (rc == SWG_OK) rc = swg_set_query(ctx, qidx, lq);
-    if (rc == SWG_OK) {
-        rc = swg_db_pack(didx, db.seq_off, db.n, 0, 1, &pdb);
-        if (rc != SWG_OK) fprintf(stderr, "Error: %s\n", swg_global_error());
-    }
-    if (rc == SWG_OK) rc = swg_db_upload(ctx, pdb);
-    if (rc == SWG_OK) rc = swg_search(ctx, pdb, scores, hits, (size_t)topk, &n_hits, &st);
-    if (rc != SWG_OK) {
-        fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
-        return EXIT_FAILURE;
+    double total_ms = 0.0;
+    swg_ctx *ctx = NULL;
+    swg_db *pdb = NULL;
+    swg_group *grp = NULL;
+    if (gpus > 0) {
+        /* database sharded over several GPUs of this process */
+        swg_stats *st = (swg_stats *)calloc((size_t)gpus, sizeof(swg_stats));
+        int rc = swg_group_create(NULL, (int)gpus, 0, &grp);
+        if (rc != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", swg_global_error());
+            return EXIT_FAILURE;
+        }
+        rc = swg_group_set_scoring(grp, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
+        if (rc == SWG_OK) rc = swg_group_set_query(grp, qidx, lq);
+        if (rc == SWG_OK) rc = swg_group_load(grp, didx, db.seq_off, db.n);
+        if (rc == SWG_OK) rc = swg_group_search(grp, scores, hits, (size_t)topk, &n_hits, st);
+        if (rc != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", swg_group_last_error(grp));
+            return EXIT_FAILURE;
+        }
+        for (long g = 0; g < gpus; g++)
+            if (st[g].total_ms > total_ms) total_ms = st[g].total_ms; /* the GPUs run side by side */
+        free(st);
+    } else {
+        swg_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.device = (int)gpu;
+        if (swg_create(&cfg, &ctx) != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", swg_global_error());
+            return EXIT_FAILURE;
+        }
+        swg_stats st;
+        memset(&st, 0, sizeof st);
+        int rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
+        if (rc == SWG_OK) rc = swg_set_query(ctx, qidx, lq);
+        if (rc == SWG_OK) {
+            rc = swg_db_pack(didx, db.seq_off, db.n, 0, 1, &pdb);
+            if (rc != SWG_OK) fprintf(stderr, "Error: %s\n", swg_global_error());
+        }
+        if (rc == SWG_OK) rc = swg_db_upload(ctx, pdb);
+        if (rc == SWG_OK) rc = swg_search(ctx, pdb, scores, hits, (size_t)topk, &n_hits, &st);
+        if (rc != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
+            return EXIT_FAILURE;
+        }
+        total_ms = st.total_ms;
     }
 
     /* reference src/tools/sw_cmdline.c:38-75: per 16 records the query lines, then per record */
@@ -204,7 +233,7 @@ int main(int argc, char **argv)
         printf("score: %i\n\n", scores[i]);
     }
     /* reference src/alignment_cmdline.c:529-530; the time is the device time of the fill */
-    printf("Total Time: %f\n", st.total_ms * 1e-3);
+    printf("Total Time: %f\n", total_ms * 1e-3);
     printf("Total Entries: %lu\n", (unsigned long)db.n);
     if (topk > 0) {
         printf("Top %lu hits (score, entry, name):\n", (unsigned long)n_hits);
@@ -214,6 +243,7 @@ int main(int argc, char **argv)
     fflush(stdout);
     swg_db_free(pdb);
     swg_destroy(ctx);
+    swg_group_destroy(grp);
     swg_seqs_free(&q);
     swg_seqs_free(&db);
     free(qidx);

@@ -104,6 +104,11 @@ def test_cli_config1_against_oracle(swg, orc, tmp_path):
     exp = orc.topk(want2.astype(np.int32), 5)
     assert top == ["%d\t%d\t%s" % (s, i, names[i]) for s, i in exp]
 
+    # the multi-GPU route of the tool (one device here): same stream of entries
+    r1 = _run("--substitution_matrix", B62, "--gpus", "1", "--topk", "3", "--files", str(qf), str(df))
+    assert r1.returncode == 0, r1.stderr
+    assert {int(m.group(1)): int(m.group(2)) for m in ENTRY_RX.finditer(r1.stdout)} == dict(enumerate(want))
+
     # an illegal residue: the reference's message and exit status 1
     bad = tmp_path / "bad.fasta"
     bad.write_text(">x\nAC-DE\n")

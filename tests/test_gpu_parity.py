@@ -394,3 +394,24 @@ def test_long_tail_database(swg, ctx, orc):
         assert hits == orc.topk(want, 5)
         db.close()
     _reset_options(ctx)
+
+
+def test_group_with_rccl_merge(swg, orc):
+    """swg_group on this box's one GPU with the collective forced: shard packing, concurrent
+    begin/end, the RCCL max-all-reduce of the hit keys and the final merge all run; results are
+    the oracle's.  (More devices only add segments to the same all-reduce.)"""
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(21, 150)
+    flat, off = swg.synth_db(21, 1500, max_len=700)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    for force in (False, True):
+        grp = swg.Group([0], force_collective=force)
+        grp.set_scoring(sc, -2, -1)
+        grp.set_query(q)
+        grp.load(flat, off)
+        scores, hits, stats = grp.search(k=40)
+        assert np.array_equal(scores, want) and hits == orc.topk(want, 40)
+        none, hits2, _ = grp.search(want_scores=False, k=7)
+        assert none is None and hits2 == orc.topk(want, 7)
+        assert len(stats) == 1 and stats[0]["cells"] == len(q) * len(flat)
+        grp.close()
