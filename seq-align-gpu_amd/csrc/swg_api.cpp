@@ -536,10 +536,50 @@ static int diag_fill_ms(swg_ctx *ctx, bool two_ends, double *out)
     return SWG_OK;
 }
 
+// Launches the systolic int16/int32 fill of one plan over the whole database (events ev[1], ev[2]).
+static int launch_systolic(swg_ctx *ctx, const swg_db *db, const Plan &pl, int go, int ge)
+{
+    hipStream_t s = ctx->stream;
+    SwgFillParams p;
+    memset(&p, 0, sizeof p);
+    p.residues = db->d_packed;
+    p.bin_off = db->d_bin_off;
+    p.bin_nblk = db->d_bin_nblk;
+    p.n_bins = db->n_bins;
+    p.scores = db->d_scores;
+    p.scratch = ctx->d_scratch;
+    p.profile = ctx->d_profile[pl.bits == 16 ? 0 : 1];
+    p.queue = db->d_counters + 0;
+    p.n_items = pl.bits == 16 ? db->n_bins : db->n_bins * 2;
+    p.npass = (uint32_t)pl.npass;
+    if (pl.bits == 16) {
+        const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
+        p.go = (int32_t)(g | (g << 16));
+        p.ge = (int32_t)(e | (e << 16));
+    } else {
+        p.go = go;
+        p.ge = ge;
+    }
+    p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * pl.info.nb;
+    HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
+    HIP_TRY(ctx, swg_launch_fill(pl.bits, pl.variant, pl.W, pl.workgroups, p, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
+    return SWG_OK;
+}
+
+static int prepare_systolic(swg_ctx *ctx, const swg_db *db, const Plan &pl)
+{
+    int rc = ensure_profile(ctx, pl);
+    if (rc != SWG_OK) return rc;
+    const size_t need = pl.npass > 1 ? (size_t)pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * pl.info.nb : 0;
+    return ensure_scratch(ctx, need);
+}
+
 // First search of a query length on a database: the cost model ranks the geometries, the few
 // best are timed once on this device (each is a complete, valid fill) and the fastest is kept.
-static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, SwgDiagWork *best)
+static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, SwgTuned *tuned)
 {
+    SwgDiagWork *best = &tuned->wk;
     std::vector<SwgDiagWork> cands;
     if (swg_plan_diag_candidates(db, lq, ctx->n_cu, 0, 0, 0, 0, true, &cands) <= 0) return SWG_ERR_ARG;
     // distinct (K, G, W, split) among the best-ranked
@@ -610,6 +650,35 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
                 *best = *same;
                 best->plan[0].est_ms = ms;
             }
+        }
+    }
+    tuned->engine = 2;
+    tuned->ms = best_ms;
+    // third stage: the systolic engine has less bookkeeping per row and wins on large databases,
+    // where its coarse work units (128 sequences x all waves of a workgroup) no longer matter
+    const long keep_cols = ctx->opt_cols;
+    for (int v = 0; v < swg_num_variants(16); ++v) {
+        Plan pl;
+        memset(&pl, 0, sizeof pl);
+        ctx->opt_cols = swg_variant_info(16, v).K;
+        int rc = make_plan(ctx, 16, db->n_bins, &pl);
+        ctx->opt_cols = keep_cols;
+        if (rc != SWG_OK) continue;
+        if ((rc = prepare_systolic(ctx, db, pl)) != SWG_OK) return rc;
+        double ms_min = 1e300;
+        for (int rep = 0; rep < 2; ++rep) {
+            HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, 64, ctx->stream));
+            if ((rc = launch_systolic(ctx, db, pl, go, ge)) != SWG_OK) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            double ms = 0;
+            if ((rc = diag_fill_ms(ctx, false, &ms)) != SWG_OK) return rc;
+            ms_min = std::min(ms_min, ms);
+        }
+        if (ms_min < tuned->ms) {
+            tuned->ms = ms_min;
+            tuned->engine = 1;
+            tuned->systolic_K = pl.K;
         }
     }
     return SWG_OK;
@@ -689,23 +758,36 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     if (rc != SWG_OK && !(bits == 16 && ctx->opt_engine != 1)) return rc;
     // int16: the diagonal engine unless the systolic one is asked for
     SwgDiagWork wk;
-    bool use_diag = false;
+    bool use_diag = false, tuned_systolic = false;
     if (bits == 16 && ctx->opt_engine != 1) {
         const bool free_geometry = ctx->opt_cols == 0 && ctx->opt_group == 0 && ctx->opt_max_waves == 0 &&
                                    ctx->opt_long_split == 0 && ctx->opt_workgroups == 0;
         swg_db *mdb = const_cast<swg_db *>(db);
         auto it = free_geometry ? mdb->tuned.find(lq) : mdb->tuned.end();
-        if (it != mdb->tuned.end()) {
-            wk = it->second;
-            use_diag = true;
-        } else if (free_geometry && ctx->opt_autotune && db->n_local >= 4096 && db->n_local <= (4u << 20)) {
-            use_diag = autotune_diag(ctx, mdb, lq, go, ge, &wk) == SWG_OK && wk.n_classes > 0;
-            if (use_diag) mdb->tuned[lq] = wk;
+        if (it == mdb->tuned.end() && free_geometry && ctx->opt_autotune && ctx->opt_engine == 0 &&
+            db->n_local >= 4096 && db->n_local <= (4u << 20)) {
+            SwgTuned tn;
+            if (autotune_diag(ctx, mdb, lq, go, ge, &tn) == SWG_OK && tn.wk.n_classes > 0)
+                it = mdb->tuned.insert(std::make_pair((uint64_t)lq, tn)).first;
         }
-        if (!use_diag)
+        if (it != mdb->tuned.end()) {
+            if (it->second.engine == 1 && ctx->opt_engine == 0) {
+                // the systolic engine measured faster for this database and query length
+                const long keep = ctx->opt_cols;
+                ctx->opt_cols = it->second.systolic_K;
+                rc = make_plan(ctx, 16, n_bins, &main_pl);
+                ctx->opt_cols = keep;
+                if (rc != SWG_OK) return rc;
+                tuned_systolic = true;
+            } else {
+                wk = it->second.wk;
+                use_diag = true;
+            }
+        }
+        if (!use_diag && !tuned_systolic)
             use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
                                           ctx->opt_long_split, ctx->opt_workgroups == 0, &wk) > 0;
-        if (!use_diag && ctx->opt_engine == 2)
+        if (!use_diag && !tuned_systolic && ctx->opt_engine == 2)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
         if (use_diag && ctx->opt_workgroups > 0) {
             SwgDiagPlan &d0 = wk.plan[0];
@@ -713,7 +795,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             d0.workgroups = (int)std::min<long>(ctx->opt_workgroups, d0.workgroups);
             d0.n_streams = (uint32_t)((uint64_t)d0.workgroups * per_wg);
         }
-        if (!use_diag && rc != SWG_OK) return rc;
+        if (!use_diag && !tuned_systolic && rc != SWG_OK) return rc;
     }
     const SwgDiagPlan &dpl = wk.plan[0];
     // can an int16 score saturate at all?  score <= min(lq, longest) * max(S)

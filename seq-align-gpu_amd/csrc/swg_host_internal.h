@@ -46,6 +46,14 @@ struct SwgDiagWork {
     uint64_t pair_begin[2] = {0, 0}, pair_end[2] = {0, 0};
 };
 
+// What the autotuner keeps per query length: the engine and its geometry.
+struct SwgTuned {
+    int engine = 2;    // 1 systolic, 2 diagonal
+    int systolic_K = 0; // engine 1: columns per wavefront of the chosen instantiation
+    double ms = 0;
+    SwgDiagWork wk;    // engine 2
+};
+
 struct swg_db {
     // host image
     size_t n_total = 0;             // sequences given to swg_db_pack
@@ -62,7 +70,7 @@ struct swg_db {
     std::vector<uint8_t> codes;     // residue bytes (index<<3) by sorted rank, back to back
     std::vector<uint64_t> code_off; // [n_bins*128+1]
     SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs
-    std::map<uint64_t, SwgDiagWork> tuned; // query length -> geometry that measured fastest on this device
+    std::map<uint64_t, SwgTuned> tuned; // query length -> engine + geometry that measured fastest on this device
     // device image (valid after swg_db_upload)
     int device = -1;
     uint32_t *d_packed = nullptr;
