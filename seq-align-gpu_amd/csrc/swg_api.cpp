@@ -221,9 +221,11 @@ extern "C" int swg_set_query(swg_ctx *ctx, const int8_t *idx, size_t lq)
         HIP_TRY(ctx, hipMalloc(&ctx->d_query, lq));
         ctx->d_query_cap = lq;
     }
+    // No wait here: the copy and the profile build that consumes it are ordered on the context's
+    // stream behind any search still in flight, so a caller can stream queries against a resident
+    // database (set_query, search_begin, set_query, search_begin, search_end, ...).
     ctx->query.assign(idx, idx + lq);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_query, ctx->query.data(), lq, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->epoch++;
     return SWG_OK;
 }

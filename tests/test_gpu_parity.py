@@ -415,3 +415,27 @@ def test_group_with_rccl_merge(swg, orc):
         assert none is None and hits2 == orc.topk(want, 7)
         assert len(stats) == 1 and stats[0]["cells"] == len(q) * len(flat)
         grp.close()
+
+
+def test_queries_streamed_against_resident_database(swg, ctx, orc):
+    """Many queries, one resident database: each query is set and queued while the previous
+    search is still in flight (many-to-many use); every result is the oracle's."""
+    sc = swg.load_scoring("BLOSUM45")
+    flat, off = swg.synth_db(31, 2500, max_len=900)
+    ctx.set_scoring(sc, -3, -1)
+    _reset_options(ctx)
+    db = swg.Database(flat, off).upload(ctx)
+    queries = [swg.synth_query(40 + i, L) for i, L in enumerate((33, 700, 128, 1, 257, 64, 1500, 90))]
+    pending, got = None, []
+    for q in queries:
+        ctx.set_query(q)
+        t = ctx.search_begin(db, k=10, want_scores=True)
+        if pending is not None:
+            got.append(ctx.search_end(pending))
+        pending = t
+    got.append(ctx.search_end(pending))
+    for q, (scores, hits, st) in zip(queries, got):
+        want = orc.score_db(q, flat, off, sc.table(), -3, -1)
+        assert np.array_equal(scores, want), len(q)
+        assert hits == orc.topk(want, 10) and st["cells"] == len(q) * len(flat)
+    db.close()
