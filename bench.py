@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--long-split", type=int, default=0, help="-1 off, 0 auto, else rows threshold of the long class")
     ap.add_argument("--long-cols", type=int, default=0, help="experiment: columns per lane of the long class")
     ap.add_argument("--long-group", type=int, default=0, help="experiment: lanes per pair of the long class")
+    ap.add_argument("--lq", type=int, default=0, help="experiment: override the query length of the config")
+    ap.add_argument("--nseq", type=int, default=0, help="experiment: override the sequence count of the config")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queuing the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,7 +87,11 @@ def main():
             dist.barrier()
     swg = swg_loader.load()
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.lq:
+        cfg["lq"] = args.lq
+    if args.nseq:
+        cfg["n"] = args.nseq
     lq, n = cfg["lq"], cfg["n"]
     sc = swg.load_scoring(cfg["matrix"])
     seed = 0x5EED0000 + args.config
