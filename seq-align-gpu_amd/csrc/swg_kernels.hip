@@ -931,7 +931,6 @@ const Variant *variants16(int *n)
         make_variant<CellsI16<16>, 16, 16, 16>(),
         make_variant<CellsI16<48>, 48, 8, 16>(),
         make_variant<CellsI16<24>, 24, 16, 16>(),
-        make_variant<CellsI16<64>, 64, 8, 16>(),
     };
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
