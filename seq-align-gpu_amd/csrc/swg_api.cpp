@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -175,6 +176,11 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         g_swg_long_group = value;
     } else if (!strcmp(key, "autotune")) {
         ctx->opt_autotune = value != 0;
+    } else if (!strcmp(key, "work_queue")) {
+        ctx->opt_dynamic = value != 0;
+    } else if (!strcmp(key, "prio_share")) {
+        if (value < 0) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "prio_share must be >= 0 (percent)");
+        ctx->opt_prio_share = value;
     } else if (!strcmp(key, "long_split")) {
         if (value < -1) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "long_split must be -1 (off), 0 (auto) or a row count");
         ctx->opt_long_split = value;
@@ -249,6 +255,9 @@ void swg_db_release_device(swg_db *db)
         (void)hipFree(b.d_hist);
         b = swg_db::Bufs();
     }
+    (void)hipFree(db->ptok.d_tok);
+    (void)hipFree(db->ptok.d_pair_off);
+    db->ptok = SwgPairTokens();
     for (SwgDiagLayout &L : db->diag) {
         (void)hipFree(L.d_tok);
         (void)hipFree(L.d_stream_off);
@@ -438,6 +447,66 @@ static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, int cls, const SwgDiagPl
     return SWG_OK;
 }
 
+// Pair-major tokens, built once per database on first use by the diagonal engine.
+static int ensure_pair_tokens(swg_ctx *ctx, swg_db *db)
+{
+    SwgPairTokens &T = db->ptok;
+    if (T.tried) return SWG_OK;
+    T.tried = true;
+    std::vector<uint32_t> tok;
+    try {
+        if (swg_build_pair_tokens(db, &tok, &T.pair_blocks_prefix) != 0) return SWG_OK; // too large: static streams
+    } catch (const std::bad_alloc &) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "pair tokens: out of host memory");
+    }
+    T.total_blocks = T.pair_blocks_prefix.back();
+    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(8, tok.size() * 4)));
+    HIP_TRY(ctx, hipMalloc(&T.d_pair_off, T.pair_blocks_prefix.size() * 4));
+    if (!tok.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(T.d_tok, tok.data(), tok.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(T.d_pair_off, T.pair_blocks_prefix.data(), T.pair_blocks_prefix.size() * 4,
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    T.ok = true;
+    return SWG_OK;
+}
+
+// Single-pass classes take their pairs off a work queue; multi-pass ones keep static streams
+// (a pair's edge spill has to be read back by the lane group that wrote it).
+static bool diag_class_is_dynamic(const swg_ctx *ctx, const swg_db *db, const SwgDiagPlan &pl)
+{
+    return pl.npass == 1 && ctx->opt_dynamic != 0 && db->ptok.ok;
+}
+
+// Workgroups to launch for class c.  Work-queue kernels are persistent: a workgroup that is not
+// resident from the start only gets in when another one has run out of pairs, so when the long
+// class runs beside the bulk the bulk leaves it its wave slots (one per SIMD per long workgroup).
+static int diag_class_workgroups(const swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int c)
+{
+    const SwgDiagPlan &pl = wk.plan[c];
+    if (c != 0 || wk.n_classes != 2 || !diag_class_is_dynamic(ctx, db, pl) ||
+        !diag_class_is_dynamic(ctx, db, wk.plan[1]))
+        return pl.workgroups;
+    const SwgKernelInfo info = swg_diag_variant_info(pl.variant);
+    const size_t lds = swg_diag_dyn_lds_bytes(pl.K, pl.G, pl.W);
+    const int per_cu = std::max(1, std::min<int>(info.max_waves / pl.W, (int)((160 * 1024) / lds)));
+    const int capacity = ctx->n_cu * per_cu;
+    const int displaced = (wk.plan[1].workgroups * wk.plan[1].W + pl.W - 1) / pl.W;
+    return std::max(1, std::min(pl.workgroups, capacity - displaced));
+}
+
+// 4-row token blocks and lane groups of class c, for the statistics
+static uint64_t diag_class_blocks(const swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int c)
+{
+    if (!diag_class_is_dynamic(ctx, db, wk.plan[c])) return db->diag[c].total_blocks;
+    return (uint64_t)db->ptok.pair_blocks_prefix[wk.pair_end[c]] - db->ptok.pair_blocks_prefix[wk.pair_begin[c]];
+}
+static uint32_t diag_class_streams(const swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int c)
+{
+    if (!diag_class_is_dynamic(ctx, db, wk.plan[c])) return db->diag[c].n_streams;
+    return (uint32_t)(diag_class_workgroups(ctx, db, wk, c) * wk.plan[c].W * (64 / wk.plan[c].G));
+}
+
 static int ensure_scratch(swg_ctx *ctx, size_t dwords)
 {
     if (dwords <= ctx->d_scratch_cap) return SWG_OK;
@@ -458,9 +527,15 @@ static int diag_profile_slot(const SwgDiagPlan &pl) { return pl.K % 4 == 0 ? 0 :
 static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
 {
     uint32_t ncols[3] = {0, 0, 0};
-    for (int c = 0; c < wk.n_classes; ++c) {
-        int rc = ensure_diag_layout(ctx, db, c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
+    if (ctx->opt_dynamic) {
+        int rc = ensure_pair_tokens(ctx, db);
         if (rc != SWG_OK) return rc;
+    }
+    for (int c = 0; c < wk.n_classes; ++c) {
+        if (!diag_class_is_dynamic(ctx, db, wk.plan[c])) {
+            int rc = ensure_diag_layout(ctx, db, c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
+            if (rc != SWG_OK) return rc;
+        }
         const int slot = diag_profile_slot(wk.plan[c]);
         ncols[slot] = std::max<uint32_t>(ncols[slot], (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
     }
@@ -480,6 +555,16 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
     hipStream_t s = ctx->stream;
     const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
     *two_ends = false;
+    // diagnostics: SWG_TRACE=<file> dumps one line per wavefront (class, workgroup, wave, start and
+    // end in 10 ns ticks, blocks of its longest stream) for every diagonal fill
+    static const char *trace_path = getenv("SWG_TRACE");
+    uint64_t *d_trace[2] = {nullptr, nullptr};
+    if (trace_path)
+        for (int c = 0; c < wk.n_classes; ++c) {
+            const size_t bytes = (size_t)wk.plan[c].workgroups * wk.plan[c].W * 3 * 8;
+            HIP_TRY(ctx, hipMalloc(&d_trace[c], bytes));
+            HIP_TRY(ctx, hipMemsetAsync(d_trace[c], 0, bytes, s));
+        }
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
     if (wk.n_classes == 2) {
         // fork: the long pairs start first, on their own stream, beside the bulk
@@ -489,6 +574,30 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
     for (int c = wk.n_classes - 1; c >= 0; --c) {
         const SwgDiagLayout &L = db->diag[c];
         const SwgDiagPlan &pl = wk.plan[c];
+        if (diag_class_is_dynamic(ctx, db, pl)) {
+            const SwgPairTokens &T = db->ptok;
+            SwgDiagDynParams q;
+            memset(&q, 0, sizeof q);
+            q.tok = T.d_tok;
+            q.pair_off = T.d_pair_off;
+            q.q_begin = (uint32_t)wk.pair_begin[c];
+            q.q_end = (uint32_t)wk.pair_end[c];
+            q.queue = db->d_counters + 8 + c; // zeroed with the other counters before the fill
+            q.profile = ctx->d_profile[diag_profile_slot(pl)];
+            q.scores = db->d_scores;
+            q.G = (uint32_t)pl.G;
+            q.go = g | (g << 16);
+            q.ge = e | (e << 16);
+            // the long class always runs at raised priority; in the bulk, a pair that alone is as much
+            // work as an average lane group's whole share
+            const uint64_t blocks = T.pair_blocks_prefix[wk.pair_end[c]] - T.pair_blocks_prefix[wk.pair_begin[c]];
+            const uint64_t groups = (uint64_t)diag_class_workgroups(ctx, db, wk, c) * pl.W * (64 / pl.G);
+            q.prio_blocks = c == 1 ? 0u : (uint32_t)std::max<uint64_t>(8, (uint64_t)(ctx->opt_prio_share * 0.01 * (double)blocks / (double)std::max<uint64_t>(1, groups)));
+            q.trace = d_trace[c];
+            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, pl.W, diag_class_workgroups(ctx, db, wk, c), q,
+                                             c == 1 ? ctx->stream2 : s));
+            continue;
+        }
         SwgDiagParams d;
         memset(&d, 0, sizeof d);
         d.tok = L.d_tok;
@@ -510,6 +619,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
         d.prio_blocks = c == 1 ? 0u
                         : (double)L.max_stream_blocks > 1.1 * mean_blocks ? (uint32_t)(0.75 * (double)L.max_stream_blocks)
                                                                           : 0xFFFFFFFFu;
+        d.trace = d_trace[c];
         HIP_TRY(ctx, swg_launch_diag(pl.variant, pl.npass > 1, pl.W, pl.workgroups, pl.lds_bytes, d,
                                      c == 1 ? ctx->stream2 : s));
     }
@@ -521,6 +631,22 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
         *two_ends = true;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
+    if (trace_path) {
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        FILE *f = fopen(trace_path, "a");
+        if (f) fprintf(f, "# fill K=%d G=%d W=%d wgs=%d classes=%d\n", wk.plan[0].K, wk.plan[0].G, wk.plan[0].W,
+                       wk.plan[0].workgroups, wk.n_classes);
+        for (int c = 0; c < wk.n_classes; ++c) {
+            const size_t n = (size_t)wk.plan[c].workgroups * wk.plan[c].W;
+            std::vector<uint64_t> h(n * 3);
+            HIP_TRY(ctx, hipMemcpy(h.data(), d_trace[c], n * 24, hipMemcpyDeviceToHost));
+            (void)hipFree(d_trace[c]);
+            for (size_t i = 0; f && i < n; ++i)
+                fprintf(f, "%d %zu %zu %llu %llu %llu\n", c, i / wk.plan[c].W, i % wk.plan[c].W,
+                        (unsigned long long)h[3 * i], (unsigned long long)h[3 * i + 1], (unsigned long long)h[3 * i + 2]);
+        }
+        if (f) fclose(f);
+    }
     return SWG_OK;
 }
 
@@ -583,7 +709,8 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
 {
     SwgDiagWork *best = &tuned->wk;
     std::vector<SwgDiagWork> cands;
-    if (swg_plan_diag_candidates(db, lq, ctx->n_cu, 0, 0, 0, 0, true, &cands) <= 0) return SWG_ERR_ARG;
+    const bool work_queue = ctx->opt_dynamic != 0 && db->ptok.ok;
+    if (swg_plan_diag_candidates(db, lq, ctx->n_cu, 0, 0, 0, 0, true, work_queue, &cands) <= 0) return SWG_ERR_ARG;
     // distinct (K, G, W, split) among the best-ranked
     std::vector<SwgDiagWork> pick;
     for (const SwgDiagWork &c : cands) {
@@ -605,6 +732,7 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
         for (int rep = 0; rep < 2; ++rep) {
             bool two = false;
             HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, 64, ctx->stream));
             rc = launch_diag(ctx, db, c, go, ge, &two);
             if (rc != SWG_OK) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -629,13 +757,17 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
     if (best->n_classes == 2) {
         const SwgDiagWork base = *best;
         const uint64_t n_pairs = swg_db_pair_count(db);
-        const double mean_rows = (double)swg_db_pair_rows(db, 0, n_pairs, nullptr) / (double)base.plan[0].n_streams;
-        const double fractions[] = {0.25, 0.45, 0.8, 1.0, 1.3, 1.7};
-        for (double f : fractions) {
-            const long thr = (long)std::max(64.0, f * mean_rows);
+        const bool dyn = diag_class_is_dynamic(ctx, db, base.plan[0]);
+        // static streams: multiples of a stream's mean share; work queue: around the model's cut
+        const double unit = dyn ? (double)(2ull + db->lens[2 * base.pair_end[1]])
+                                : (double)swg_db_pair_rows(db, 0, n_pairs, nullptr) / (double)base.plan[0].n_streams;
+        const double fr_static[] = {0.25, 0.45, 0.8, 1.0, 1.3, 1.7};
+        const double fr_dyn[] = {0.6, 0.75, 0.88, 1.15, 1.35, 1.7};
+        for (int i = 0; i < 6; ++i) {
+            const long thr = (long)std::max(64.0, (dyn ? fr_dyn[i] : fr_static[i]) * unit);
             std::vector<SwgDiagWork> alt;
             if (swg_plan_diag_candidates(db, lq, ctx->n_cu, base.plan[0].K, base.plan[0].G, base.plan[0].W, thr, true,
-                                         &alt) <= 0)
+                                         work_queue, &alt) <= 0)
                 continue;
             const SwgDiagWork *same = nullptr;
             for (const SwgDiagWork &c : alt)
@@ -762,6 +894,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     SwgDiagWork wk;
     bool use_diag = false, tuned_systolic = false;
     if (bits == 16 && ctx->opt_engine != 1) {
+        if (ctx->opt_dynamic && (rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
         const bool free_geometry = ctx->opt_cols == 0 && ctx->opt_group == 0 && ctx->opt_max_waves == 0 &&
                                    ctx->opt_long_split == 0 && ctx->opt_workgroups == 0;
         swg_db *mdb = const_cast<swg_db *>(db);
@@ -788,7 +921,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         }
         if (!use_diag && !tuned_systolic)
             use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
-                                          ctx->opt_long_split, ctx->opt_workgroups == 0, &wk) > 0;
+                                          ctx->opt_long_split, ctx->opt_workgroups == 0,
+                                          ctx->opt_dynamic != 0 && db->ptok.ok, &wk) > 0;
         if (!use_diag && !tuned_systolic && ctx->opt_engine == 2)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
         if (use_diag && ctx->opt_workgroups > 0) {
@@ -1012,15 +1146,15 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         st.group_lanes = dpl.G;
         st.waves = dpl.W;
         st.passes = dpl.npass;
-        st.workgroups = dpl.workgroups;
-        st.streams = (int32_t)db->diag[0].n_streams;
-        st.cells_padded = 2ull * dpl.npass * dpl.G * dpl.K * db->diag[0].total_blocks * 4ull;
+        st.workgroups = diag_class_workgroups(ctx, db, wk, 0);
+        st.streams = (int32_t)diag_class_streams(ctx, db, wk, 0);
+        st.cells_padded = 2ull * dpl.npass * dpl.G * dpl.K * diag_class_blocks(ctx, db, wk, 0) * 4ull;
         if (wk.n_classes == 2) {
             const SwgDiagPlan &lp = wk.plan[1];
             st.long_pairs = (int32_t)(wk.pair_end[1] - wk.pair_begin[1]);
             st.long_cols_per_lane = lp.K;
-            st.long_streams = (int32_t)db->diag[1].n_streams;
-            st.cells_padded += 2ull * lp.npass * lp.G * lp.K * db->diag[1].total_blocks * 4ull;
+            st.long_streams = (int32_t)diag_class_streams(ctx, db, wk, 1);
+            st.cells_padded += 2ull * lp.npass * lp.G * lp.K * diag_class_blocks(ctx, db, wk, 1) * 4ull;
         }
     } else if (bits == 32 && use_diag32) {
         st.engine = 2;

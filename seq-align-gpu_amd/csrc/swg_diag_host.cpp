@@ -52,7 +52,7 @@ static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 18.0 : 
 long g_swg_long_cols = 0;  // experiment switch: restrict the long class to this K (0 = free)
 long g_swg_long_group = 0; // experiment switch: restrict the long class to this G (0 = free)
 
-static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_cycles, SwgDiagPlan *lp)
+static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_cycles, bool dynamic, SwgDiagPlan *lp)
 {
     bool ok = false, ok_fit = false;
     double best_cost = 1e300, best_depth = 1e300;
@@ -61,16 +61,18 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
     for (int v = 0; v < swg_num_diag_variants(); ++v) {
         const SwgKernelInfo info = swg_diag_variant_info(v);
         if (g_swg_long_cols > 0 && info.K != (int)g_swg_long_cols) continue;
-        // 2-column-chunk instantiations (K % 4 == 2) measured slower as the long class than the
-        // next multiple of 4 despite fewer instructions (more, narrower LDS reads per step on a
-        // latency-bound chain): only on request
-        if (g_swg_long_cols == 0 && info.K % 4 != 0) continue;
+        // with static streams the 2-column-chunk instantiations (K % 4 == 2) measured slower as the
+        // long class than the next multiple of 4 despite fewer instructions: only on request there.
+        // With the work queue they win (64 x 6 = 384 columns for a 367-column query: no padding
+        // beyond the bulk's).
+        if (!dynamic && g_swg_long_cols == 0 && info.K % 4 != 0) continue;
         for (int gi = 0; gi < 2; ++gi) {
             const int G = groups[gi];
             if (g_swg_long_group > 0 && G != (int)g_swg_long_group) continue;
             const size_t cols = (size_t)G * info.K;
             if (cols * 64 > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
+            if (dynamic && npass > 1) continue; // the queue serves single-pass classes only
             const double instr = npass * instr_per_row(info.K, G);
             const double cost = instr / (64 / G);                     // per pair-row
             const double depth = ((double)longest_rows + G) * instr * 7.5; // raised priority: ~a wave alone
@@ -99,7 +101,7 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
 }
 
 int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                             long opt_long_split, bool allow_split, std::vector<SwgDiagWork> *cands)
+                             long opt_long_split, bool allow_split, bool work_queue, std::vector<SwgDiagWork> *cands)
 {
     cands->clear();
     const uint64_t n_pairs = swg_db_pair_count(db);
@@ -121,6 +123,9 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
             const int npass = (int)((lq + cols - 1) / cols);
             const int NG = 64 / G;
             const double instr = instr_per_row(info.K, G);
+            // single-pass classes take pairs off a queue: no fixed shares, the chain that matters is
+            // the longest pair at the rate of a wavefront that gets its fair share of the SIMD
+            const bool dynamic = work_queue && npass == 1;
             for (int wps = 1; wps <= 4; ++wps) {
                 const int W = 4 * wps;
                 if (W > info.max_waves) continue;
@@ -139,6 +144,11 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                         const double frac = split == 3 ? 0.6 : 0.33;
                         uint64_t thr = opt_long_split > 0 ? (uint64_t)opt_long_split
                                                           : (uint64_t)(frac * (double)rows_all / (double)streams0);
+                        if (dynamic && opt_long_split <= 0) {
+                            // longest pair a fair-share wavefront finishes within the whole search
+                            const double all_cycles = (double)rows_all / NG * instr * cps / simds;
+                            thr = (uint64_t)((split == 3 ? 0.65 : 0.9) * all_cycles / (instr * cps * eff_wps));
+                        }
                         thr = std::max<uint64_t>(thr, 64);
                         if (longest <= thr) continue;
                         n_long = swg_db_pairs_longer_than(db, thr);
@@ -168,11 +178,13 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                             lp.npass = npass;
                             lp.W = 4;
                             lp.lds_bytes = lds;
-                        } else if (!long_class_geometry(lq, longest_long, 0.8 * bulk_cycles, &lp)) {
+                        } else if (!long_class_geometry(lq, longest_long, 0.8 * bulk_cycles, dynamic, &lp)) {
                             continue;
                         }
                         const uint64_t lspw = 4ull * (64 / lp.G);
-                        lstreams = std::max<uint64_t>(1, std::min<uint64_t>((n_long + 1) / 2, (uint64_t)n_cu * lspw));
+                        // static: two pairs per stream to balance; queue: a wavefront on every SIMD
+                        lstreams = std::max<uint64_t>(1, std::min<uint64_t>(dynamic ? n_long : (n_long + 1) / 2,
+                                                                            (uint64_t)n_cu * lspw));
                         lstreams = (lstreams + lspw - 1) / lspw * lspw;
                         const double linstr = instr_per_row(lp.K, lp.G);
                         work += (double)rows_long / (64 / lp.G) * lp.npass * linstr * cps;
@@ -220,13 +232,31 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
 }
 
 int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                       long opt_long_split, bool allow_split, SwgDiagWork *wk)
+                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk)
 {
     std::vector<SwgDiagWork> c;
     wk->n_classes = 0;
-    if (swg_plan_diag_candidates(db, lq, n_cu, opt_cols, opt_group, opt_waves, opt_long_split, allow_split, &c) > 0)
+    if (swg_plan_diag_candidates(db, lq, n_cu, opt_cols, opt_group, opt_waves, opt_long_split, allow_split, work_queue,
+                                 &c) > 0)
         *wk = c[0];
     return wk->n_classes;
+}
+
+// Tokens of one pair of sequences (two reset rows, then one row per residue of the longer
+// one); returns the number of 4-row blocks.  `t` must be zero-filled.
+static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint16_t *t)
+{
+    const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
+    const uint32_t lx = db->lens[2 * p];
+    const bool has_y = 2 * p + 1 < n_slots && db->order[2 * p + 1] != 0xFFFFFFFFu;
+    const uint32_t ly = has_y ? db->lens[2 * p + 1] : 0;
+    const uint8_t *cx = db->codes.data() + db->code_off[2 * p];
+    const uint8_t *cy = has_y ? db->codes.data() + db->code_off[2 * p + 1] : nullptr;
+    t[0] = 1; // reset rows: flag bit0, padding residue for both sequences
+    t[1] = 1;
+    for (uint32_t j = 0; j < lx; ++j)
+        t[2 + j] = (uint16_t)(cx[j] | (j + 1 == lx ? 2u : 0u) | (j < ly ? (uint32_t)cy[j] << 8 : 0u));
+    return (2ull + lx + 3) / 4;
 }
 
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
@@ -291,18 +321,26 @@ void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_
 #pragma omp parallel for schedule(dynamic, 16)
     for (long long s = 0; s < (long long)n_streams; ++s) {
         uint16_t *t = base + L->stream_off[s] * 4;
-        for (uint32_t i = L->stream_pair_off[s]; i < L->stream_pair_off[s + 1]; ++i) {
-            const size_t p = L->stream_pairs[i];
-            const uint32_t lx = db->lens[2 * p];
-            const bool has_y = 2 * p + 1 < n_slots && db->order[2 * p + 1] != 0xFFFFFFFFu;
-            const uint32_t ly = has_y ? db->lens[2 * p + 1] : 0;
-            const uint8_t *cx = db->codes.data() + db->code_off[2 * p];
-            const uint8_t *cy = has_y ? db->codes.data() + db->code_off[2 * p + 1] : nullptr;
-            t[0] = 1; // reset rows: flag bit0, padding residue for both sequences
-            t[1] = 1;
-            for (uint32_t j = 0; j < lx; ++j)
-                t[2 + j] = (uint16_t)(cx[j] | (j + 1 == lx ? 2u : 0u) | (j < ly ? (uint32_t)cy[j] << 8 : 0u));
-            t += ((2ull + lx + 3) / 4) * 4; // rest of the last block stays padding
-        }
+        for (uint32_t i = L->stream_pair_off[s]; i < L->stream_pair_off[s + 1]; ++i)
+            t += write_pair_tokens(db, L->stream_pairs[i], t) * 4; // rest of the last block stays padding
     }
+}
+
+int swg_build_pair_tokens(const swg_db *db, std::vector<uint32_t> *tok, std::vector<uint32_t> *pair_off)
+{
+    const uint64_t n_pairs = swg_db_pair_count(db);
+    if (n_pairs >= (1ull << 31)) return -1;
+    pair_off->assign((size_t)n_pairs + 1, 0u);
+    uint64_t total = 0;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        total += (2ull + db->lens[2 * p] + 3) / 4;
+        if (total >= (1ull << 32)) return -1; // block offsets are 32-bit on the device
+        (*pair_off)[p + 1] = (uint32_t)total;
+    }
+    tok->assign((size_t)total * 2, 0u);
+    uint16_t *base = reinterpret_cast<uint16_t *>(tok->data());
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long long p = 0; p < (long long)n_pairs; ++p)
+        write_pair_tokens(db, (size_t)p, base + (size_t)(*pair_off)[p] * 4);
+    return 0;
 }

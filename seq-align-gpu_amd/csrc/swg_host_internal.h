@@ -30,6 +30,16 @@ struct SwgDiagLayout {
     uint64_t d_scratch_rows = 0;
 };
 
+// Pair-major tokens for the work-queue form of the diagonal engine: pair p of the sorted
+// order owns blocks [pair_off[p], pair_off[p+1]); independent of the launch geometry.
+struct SwgPairTokens {
+    bool tried = false, ok = false;
+    uint64_t total_blocks = 0;
+    uint2 *d_tok = nullptr;
+    uint32_t *d_pair_off = nullptr;
+    std::vector<uint32_t> pair_blocks_prefix; // host copy of pair_off
+};
+
 struct SwgDiagPlan {
     int variant, K, G, npass, W, workgroups;
     uint32_t n_streams;
@@ -69,6 +79,7 @@ struct swg_db {
     std::vector<uint32_t> packed;   // residue dwords (bins, systolic engine)
     std::vector<uint8_t> codes;     // residue bytes (index<<3) by sorted rank, back to back
     std::vector<uint64_t> code_off; // [n_bins*128+1]
+    SwgPairTokens ptok;             // pair-major tokens (work-queue form of the diagonal engine)
     SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs
     std::map<uint64_t, SwgTuned> tuned; // query length -> engine + geometry that measured fastest on this device
     // device image (valid after swg_db_upload)
@@ -127,7 +138,7 @@ struct swg_ctx {
     // query
     std::vector<int8_t> query;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150;
     // device state
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;
@@ -152,10 +163,13 @@ void swg_db_release_device(swg_db *db);
 // geometry of both classes for one query length on one device; returns the number of
 // classes (0: the diagonal engine cannot run this with the given options)
 int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                       long opt_long_split, bool allow_split, SwgDiagWork *wk);
+                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk);
 // every geometry the model considered, best estimate first (the autotuner times the first few)
 int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                             long opt_long_split, bool allow_split, std::vector<SwgDiagWork> *cands);
+                             long opt_long_split, bool allow_split, bool work_queue,
+                             std::vector<SwgDiagWork> *cands);
+// 0 on success; -1 when the database is too large for 32-bit block offsets
+int swg_build_pair_tokens(const swg_db *db, std::vector<uint32_t> *tok, std::vector<uint32_t> *pair_off);
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
                            uint32_t streams_per_wg, SwgDiagLayout *out);
 uint64_t swg_db_pair_count(const swg_db *db);

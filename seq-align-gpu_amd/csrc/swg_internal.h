@@ -48,6 +48,21 @@ struct SwgDiagParams {
     uint32_t npass, G;
     uint32_t go, ge;                 // |gap_open+gap_extend|, |gap_extend| in both halves
     uint32_t prio_blocks;            // wavefronts whose longest stream has >= this many blocks run at raised priority
+    uint64_t *trace;                 // diagnostics (SWG_TRACE): per wavefront {start, end, blocks}, or null
+};
+
+// The same fill with pairs handed out by a device-wide counter (single pass only).
+struct SwgDiagDynParams {
+    const uint2 *tok;         // pair-major token blocks (4 rows = 8 bytes each), longest pair first
+    const uint32_t *pair_off; // [n_pairs+1] block offset of each pair's tokens
+    uint32_t q_begin, q_end;  // this launch serves pairs [q_begin, q_end)
+    uint32_t *queue;          // work counter, zero before the launch
+    const uint8_t *profile;   // [G*K/ch][32][ch] int16
+    int32_t *scores;          // by sorted rank: pair p -> 2p, 2p+1
+    uint32_t G;
+    uint32_t go, ge;          // |gap_open+gap_extend|, |gap_extend| in both halves
+    uint32_t prio_blocks;     // a wavefront feeding a pair of >= this many blocks runs at raised priority
+    uint64_t *trace;          // diagnostics (SWG_TRACE) or null
 };
 
 struct SwgKernelInfo {
@@ -76,6 +91,8 @@ int swg_num_diag_variants();
 SwgKernelInfo swg_diag_variant_info(int variant); // K, max_waves (wave budget of one CU)
 hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, size_t lds_bytes,
                            const SwgDiagParams &p, hipStream_t stream);
+size_t swg_diag_dyn_lds_bytes(int K, int G, int W);
+hipError_t swg_launch_diag_dyn(int variant, int W, int workgroups, const SwgDiagDynParams &p, hipStream_t stream);
 
 // profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
 // col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.

@@ -515,6 +515,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
     }
     const uint32_t wave_nblk = __builtin_amdgcn_readfirstlane(wave_max_u32(nblk));
     const uint32_t nsteps = wave_nblk * 4u + (uint32_t)G; // >= rows + G - 1, multiple of 4
+    const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
     if (wave_nblk >= p.prio_blocks) __builtin_amdgcn_s_setprio(3);
     const uint32_t rows = nblk * 4u;
     const uint2 *tp = p.tok + boff;
@@ -620,6 +621,191 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                 }
             }
         }
+    }
+    if (p.trace && lane == 0) {
+        uint64_t *t = p.trace + (size_t)(blockIdx.x * W + w) * 3u;
+        t[0] = t_start;
+        t[1] = wall_clock64();
+        t[2] = wave_nblk;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The diagonal fill with a work queue (single pass: the query fits G*K columns)
+// ---------------------------------------------------------------------------
+// Same lanes, same step, but a lane group is not handed a fixed stream of pairs:
+// its leader lane takes the next pair off a device-wide counter when the one it
+// is feeding runs out (pairs are stored longest first, so the queue is the
+// longest-processing-time-first order).  Why: the wavefronts of a SIMD do not
+// advance at the same rate (the issue arbiter favours the oldest), so equal
+// static shares finish at very different times and the SIMDs spend the last
+// fifth of a search with one or two wavefronts -- too few to saturate the
+// issue port.  With the queue every resident wavefront stays busy until the
+// pairs are gone, whatever rate it ran at.
+//
+// The leader asks three block-steps ahead (atomic, then the pair's token range,
+// then the switch), so neither round trip is waited for.  The pair ids travel
+// from the leader to the tail lane, which writes the scores, through a small
+// ring in LDS.
+// Per lane group, in LDS after the profile: 32 dwords of bookkeeping that is only touched
+// when a pair starts or ends (keeping it out of the register file is what lets K=24 fit in
+// 128 VGPRs): [0] stage | hot<<2, [1] id of the pair asked for, [2] ids pushed, [3] ids
+// popped, [16..31] ring of pair ids.
+#define SWG_DYN_STATE 32u
+#define SWG_DYN_RING 16u
+
+template <int K, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDynParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile, then the group states
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const int G = (int)p.G;
+    const int g = lane & (G - 1);
+    const bool leader = g == 0, tail = g == G - 1;
+    constexpr int CH = CellsDiag<K>::CH;
+    const uint32_t base = (uint32_t)g * (K / CH) * CellsDiag<K>::CHUNK;
+    const uint32_t slice = (uint32_t)G * K * 64u;
+    // recomputed where it is needed (rarely) instead of living in a register
+    auto state = [&]() -> uint32_t * {
+        const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        return reinterpret_cast<uint32_t *>(smem + slice) + ((uint32_t)w * (64u / (uint32_t)G) + l / (uint32_t)G) * SWG_DYN_STATE;
+    };
+    const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
+    for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
+        *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(p.profile + o);
+    if (g < 4) state()[g] = 0u;
+    __syncthreads();
+
+    CellsDiag<K> cells;
+    cells.reset();
+    uint32_t tok = 0u, m_out = 0u, b_out = 0u, c_out = 0u;
+    uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
+    // leader lane: token blocks of the current pair still to load and where the next one is;
+    // t0/t1 hold what the last request returns until the next bookkeeping step picks it up
+    uint32_t left = 0u, bi = 0u, t0 = 0u, t1 = 0u;
+    uint32_t drain = 0u, blocks = 0u;
+    bool hot = false;
+    // wave slot on its SIMD: HW_REG_HW_ID (id 4) bits 3:0
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t word = (r & 2) ? cur.y : cur.x;
+            const uint32_t fresh = (r & 1) ? (word >> 16) : (word & 0xFFFFu);
+            uint32_t em, eb, cin;
+            if (G == 16) {
+                tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
+                em = dpp_zero<DPP_ROW_SHR1>(m_out);
+                eb = dpp_zero<DPP_ROW_SHR1>(b_out);
+                cin = dpp_zero<DPP_ROW_SHR1>(c_out);
+            } else {
+                const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
+                const uint32_t u1 = dpp_zero<DPP_WAVE_SHR1>(m_out);
+                const uint32_t u2 = dpp_zero<DPP_WAVE_SHR1>(b_out);
+                const uint32_t u3 = dpp_zero<DPP_WAVE_SHR1>(c_out);
+                if (G == 32) { // lane 32 starts a group too
+                    tok = leader ? fresh : u0;
+                    em = leader ? 0u : u1;
+                    eb = leader ? 0u : u2;
+                    cin = leader ? 0u : u3;
+                } else {
+                    tok = u0;
+                    em = u1;
+                    eb = u2;
+                    cin = u3;
+                }
+            }
+            const uint32_t ox = CH == 4 ? (tok & 0xF8u) : ((tok >> 1) & 0x7Cu);
+            const uint32_t oy = CH == 4 ? ((tok >> 8) & 0xF8u) : ((tok >> 9) & 0x7Cu);
+            const bool special = __builtin_amdgcn_ballot_w64((tok & (SWG_TOK_RESET | SWG_TOK_LAST)) != 0u) != 0ull;
+            uint32_t go_t = p.go, ge_t = p.ge;
+            if (special) {
+                const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
+                cells.best &= ~fm;
+                go_t |= fm;
+                ge_t |= fm;
+            }
+            const uint2 e = cells.row(smem, base + ox, base + oy, em, eb, go_t, ge_t);
+            c_out = pk_max_i16(cin, cells.best);
+            if (special && tail && (tok & SWG_TOK_LAST)) {
+                uint32_t *st = state();
+                const uint32_t popped = st[3];
+                const uint32_t pr = st[16u + (popped & (SWG_DYN_RING - 1u))];
+                st[3] = popped + 1u;
+                p.scores[2u * pr] = (int)(c_out & 0xFFFFu);
+                p.scores[2u * pr + 1u] = (int)(c_out >> 16);
+            }
+            m_out = e.x;
+            b_out = e.y;
+        }
+        ++blocks;
+        // The arbiter serves the oldest wavefront of a SIMD first, and these wavefronts live as long
+        // as the kernel: left alone, the youngest would crawl and the pair it holds would end long
+        // after the queue is empty.  Everyone not on the critical path therefore cycles through the
+        // lower priorities, offset by its wave slot, and gets the same share over time.
+        if (!hot && (blocks & 3u) == 0u) {
+            const uint32_t turn = ((blocks >> 2) + slot) % 3u;
+            if (turn == 0u) __builtin_amdgcn_s_setprio(0);
+            else if (turn == 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+        cur = nxt;
+        nxt = make_uint2(0u, 0u);
+        const bool low = leader && left <= 3u;
+        if (__builtin_amdgcn_ballot_w64(low) != 0ull) {
+            uint32_t *st = state();
+            uint32_t sf = st[0];
+            if (low) {
+                const uint32_t stage = sf & 3u;
+                if (stage == 2u && left == 0u) {
+                    const uint32_t nq = st[1];
+                    if (nq < p.q_end) { // the pair asked for becomes the one being fed
+                        bi = t0;
+                        left = t1 - t0;
+                        const uint32_t pushed = st[2];
+                        st[16u + (pushed & (SWG_DYN_RING - 1u))] = nq;
+                        st[2] = pushed + 1u;
+                        sf = left >= p.prio_blocks ? 4u : 0u;
+                    } else {
+                        sf = 3u;
+                    }
+                } else if (stage == 1u) {
+                    const uint32_t nq = t0;
+                    st[1] = nq;
+                    if (nq < p.q_end) {
+                        t0 = p.pair_off[nq];
+                        t1 = p.pair_off[nq + 1u];
+                    }
+                    sf = (sf & 4u) | 2u;
+                } else if (stage == 0u) {
+                    t0 = p.q_begin + atomicAdd(p.queue, 1u);
+                    sf = (sf & 4u) | 1u;
+                }
+                st[0] = sf;
+            }
+            // a wavefront feeding a long pair is on the critical path: issue priority over its neighbours
+            hot = __builtin_amdgcn_ballot_w64(leader && (sf & 4u) != 0u) != 0ull;
+            if (hot) __builtin_amdgcn_s_setprio(3);
+            // every leader out of pairs: let the rows in flight reach the tail lanes, then leave
+            if (__builtin_amdgcn_ballot_w64(leader && (sf & 3u) != 3u) == 0ull) {
+                drain += 4u;
+                if (drain >= (uint32_t)G + 12u) break;
+            }
+        }
+        if (leader && left > 0u) {
+            nxt = p.tok[bi];
+            ++bi;
+            --left;
+        }
+    }
+    if (p.trace && lane == 0) {
+        uint64_t *t = p.trace + (size_t)(blockIdx.x * W + w) * 3u;
+        t[0] = t_start;
+        t[1] = wall_clock64();
+        t[2] = blocks;
     }
 }
 
@@ -951,6 +1137,7 @@ namespace {
 struct DiagVariant {
     SwgKernelInfo info;
     void (*kernel[2])(const SwgDiagParams); // [0] single pass, [1] multi-pass
+    void (*dyn)(const SwgDiagDynParams);    // single pass, pairs off a work queue
 };
 template <int K, int MAXW> DiagVariant make_diag()
 {
@@ -964,6 +1151,7 @@ template <int K, int MAXW> DiagVariant make_diag()
     v.info.lds_fixed = 0;
     v.kernel[0] = swg_diag_kernel<K, MAXW, false>;
     v.kernel[1] = swg_diag_kernel<K, MAXW, true>;
+    v.dyn = swg_diag_dyn_kernel<K, MAXW>;
     return v;
 }
 const DiagVariant *diag_variants(int *n)
@@ -1003,6 +1191,27 @@ hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+size_t swg_diag_dyn_lds_bytes(int K, int G, int W)
+{
+    return (size_t)G * K * 64u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
+}
+
+hipError_t swg_launch_diag_dyn(int variant, int W, int workgroups, const SwgDiagDynParams &p, hipStream_t stream)
+{
+    int n;
+    const DiagVariant *v = diag_variants(&n);
+    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
+        (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
+        return hipErrorInvalidValue;
+    const size_t lds = swg_diag_dyn_lds_bytes(v[variant].info.K, (int)p.G, W);
+    auto k = v[variant].dyn;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
     return hipGetLastError();
 }
 

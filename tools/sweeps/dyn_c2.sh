@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT
+run() {
+  timeout -k 20 400 python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | grep '^{' | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+c=d['config']
+print('$*', '->', d['value'],'GCUPS K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'wgs',c['workgroups'], 'long',c.get('long_pairs'),c.get('long_cols_per_lane'),c.get('long_streams'),'pad', c['cells_padded_over_real'], 'step', d['ms_per_step'], 'fill', d['kernel_ms']['fill'])
+"
+}
+B="--no-autotune --cols 24 --group 16 --max-waves 4"
+for s in 1000 1400 2000 3000 -1; do
+for ps in 90 150 100000; do
+run $B --long-split $s --prio-share $ps
+done
+done
+run
+SWG_TRACE=gpurun_out/trace_dyn.txt python bench.py --steps 4 --warmup 0 --no-cpu-baseline $B --long-split 1400 > /dev/null 2>&1
+python tools/trace_timeline.py gpurun_out/trace_dyn.txt

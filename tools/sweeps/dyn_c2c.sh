@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT
+run() {
+  timeout -k 20 400 python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | grep '^{' | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+c=d['config']
+print('$*', '->', d['value'],'GCUPS K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'wgs',c['workgroups'], 'long',c.get('long_pairs'),c.get('long_cols_per_lane'),c.get('long_streams'),'pad', c['cells_padded_over_real'], 'step', d['ms_per_step'], 'fill', d['kernel_ms']['fill'])
+"
+}
+B="--no-autotune --cols 24 --group 16 --max-waves 4 --prio-share 100000"
+for s in 700 1000 1400; do
+run $B --long-split $s --long-group 64 --long-cols 6
+run $B --long-split $s --long-group 64 --long-cols 8
+run $B --long-split $s --long-group 32 --long-cols 12
+done

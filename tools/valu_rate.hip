@@ -128,21 +128,21 @@ template <int OP> __global__ void k(uint32_t *out, unsigned long long *cyc, int 
     }
 }
 
-extern int g_blocks;
+extern int g_blocks, g_lds, g_quick;
 template <int OP> void run(const char *name)
 {
     const int rep = 60000;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, g_lds);
     uint32_t *out; unsigned long long *cyc;
     hipMalloc(&out, 1024 * 1024 * 4); hipMalloc(&cyc, 8192 * 8);
     printf("%-28s", name);
     for (int wps = 1; wps <= 4; wps *= 2) {            // waves per SIMD (block = 4*wps waves, 1 block per CU)
         const int threads = 64 * 4 * wps, blocks = g_blocks;
-        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 96 * 1024, 0, out, cyc, rep);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), g_lds, 0, out, cyc, rep);
         hipDeviceSynchronize();
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a);
-        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 96 * 1024, 0, out, cyc, rep);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), g_lds, 0, out, cyc, rep);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         std::vector<unsigned long long> h(blocks * threads / 64), hr(blocks * threads / 64);
@@ -160,16 +160,19 @@ template <int OP> void run(const char *name)
     hipFree(out); hipFree(cyc);
 }
 
-int g_blocks = 256;
+int g_blocks = 256, g_lds = 96 * 1024, g_quick = 0;
 int main(int argc, char **argv)
 {
     if (argc > 1) g_blocks = atoi(argv[1]);
-    printf("blocks=%d\n", g_blocks);
+    if (argc > 2) g_lds = atoi(argv[2]) * 1024;  // LDS per block: 96 KB = 1 block per CU, 64 KB = 2, 32 KB = 4
+    if (argc > 3) g_quick = atoi(argv[3]);       // 1: packed ops only
+    printf("blocks=%d lds=%d\n", g_blocks, g_lds);
     run<0>("v_pk_add_i16 clamp");
     run<1>("v_pk_sub_u16 clamp");
     run<2>("v_pk_max_i16");
     run<3>("v_pk_add_u16");
     run<15>("v_pk_max_i16 (sgpr lit)");
+    if (g_quick) return 0;
     run<4>("v_perm_b32");
     run<5>("v_add_u32");
     run<6>("v_max_i32");
