@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--long-split", type=int, default=0, help="-1 off, 0 auto, else rows threshold of the long class")
     ap.add_argument("--long-cols", type=int, default=0, help="experiment: columns per lane of the long class")
     ap.add_argument("--static-streams", action="store_true", help="experiment: diagonal engine without the work queue")
+    ap.add_argument("--no-long-helps", action="store_true", help="experiment: long-class lane groups do not go on with the bulk's pairs")
     ap.add_argument("--prio-share", type=int, default=-1, help="experiment: priority threshold, percent of a lane group's mean share")
     ap.add_argument("--long-group", type=int, default=0, help="experiment: lanes per pair of the long class")
     ap.add_argument("--lq", type=int, default=0, help="experiment: override the query length of the config")
@@ -119,6 +120,8 @@ def main():
     ctx.set_option("long_group", args.long_group)
     ctx.set_option("autotune", 0 if args.no_autotune else 1)
     ctx.set_option("work_queue", 0 if args.static_streams else 1)
+    if args.no_long_helps:
+        ctx.set_option("long_helps", 0)
     if args.prio_share >= 0:
         ctx.set_option("prio_share", args.prio_share)
     db = swg.Database(flat, off).upload(ctx)

@@ -176,6 +176,8 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         g_swg_long_group = value;
     } else if (!strcmp(key, "autotune")) {
         ctx->opt_autotune = value != 0;
+    } else if (!strcmp(key, "long_helps")) {
+        ctx->opt_long_helps = value != 0;
     } else if (!strcmp(key, "work_queue")) {
         ctx->opt_dynamic = value != 0;
     } else if (!strcmp(key, "prio_share")) {
@@ -286,7 +288,7 @@ static int select_bufs(swg_ctx *ctx, swg_db *db, int slot)
     if (!b.d_scores) {
         HIP_TRY(ctx, hipMalloc(&b.d_scores, std::max<size_t>(4, ns * 4)));
         HIP_TRY(ctx, hipMalloc(&b.d_list, std::max<size_t>(4, ns * 4)));
-        HIP_TRY(ctx, hipMalloc(&b.d_counters, 64));
+        HIP_TRY(ctx, hipMalloc(&b.d_counters, SWG_COUNTER_BYTES));
         HIP_TRY(ctx, hipMalloc(&b.d_keys, SWG_TOPK_CAND_CAP * 8));
         HIP_TRY(ctx, hipMalloc(&b.d_hist, 4096 * 4));
     }
@@ -561,7 +563,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
     uint64_t *d_trace[2] = {nullptr, nullptr};
     if (trace_path)
         for (int c = 0; c < wk.n_classes; ++c) {
-            const size_t bytes = (size_t)wk.plan[c].workgroups * wk.plan[c].W * 3 * 8;
+            const size_t bytes = (size_t)wk.plan[c].workgroups * wk.plan[c].W * 4 * 8;
             HIP_TRY(ctx, hipMalloc(&d_trace[c], bytes));
             HIP_TRY(ctx, hipMemsetAsync(d_trace[c], 0, bytes, s));
         }
@@ -582,17 +584,30 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.pair_off = T.d_pair_off;
             q.q_begin = (uint32_t)wk.pair_begin[c];
             q.q_end = (uint32_t)wk.pair_end[c];
-            q.queue = db->d_counters + 8 + c; // zeroed with the other counters before the fill
+            q.queue = db->d_counters + SWG_QUEUE_WORD(c); // zeroed with the other counters before the fill
             q.profile = ctx->d_profile[diag_profile_slot(pl)];
             q.scores = db->d_scores;
             q.G = (uint32_t)pl.G;
             q.go = g | (g << 16);
             q.ge = e | (e << 16);
-            // the long class always runs at raised priority; in the bulk, a pair that alone is as much
-            // work as an average lane group's whole share
-            const uint64_t blocks = T.pair_blocks_prefix[wk.pair_end[c]] - T.pair_blocks_prefix[wk.pair_begin[c]];
-            const uint64_t groups = (uint64_t)diag_class_workgroups(ctx, db, wk, c) * pl.W * (64 / pl.G);
-            q.prio_blocks = c == 1 ? 0u : (uint32_t)std::max<uint64_t>(8, (uint64_t)(ctx->opt_prio_share * 0.01 * (double)blocks / (double)std::max<uint64_t>(1, groups)));
+            // the long class always runs at raised priority; in the bulk, a pair that alone is well
+            // above an average lane group's whole share
+            auto bulk_prio = [&]() -> uint32_t {
+                const uint64_t blocks = T.pair_blocks_prefix[wk.pair_end[0]] - T.pair_blocks_prefix[wk.pair_begin[0]];
+                const uint64_t groups = (uint64_t)diag_class_workgroups(ctx, db, wk, 0) * wk.plan[0].W * (64 / wk.plan[0].G);
+                return (uint32_t)std::max<uint64_t>(8, (uint64_t)(ctx->opt_prio_share * 0.01 * (double)blocks /
+                                                                  (double)std::max<uint64_t>(1, groups)));
+            };
+            q.prio_blocks = c == 1 ? 0u : bulk_prio();
+            if (c == 1 && ctx->opt_long_helps && diag_class_is_dynamic(ctx, db, wk.plan[0])) {
+                // when the long pairs are done their lane groups go on with the bulk's queue
+                q.q2_begin = (uint32_t)wk.pair_begin[0];
+                q.q2_end = (uint32_t)wk.pair_end[0];
+                q.queue2 = db->d_counters + SWG_QUEUE_WORD(0);
+                q.prio_blocks2 = bulk_prio();
+            }
+            q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
+            q.simd_ranks = db->d_counters + SWG_RANK_WORD(c);
             q.trace = d_trace[c];
             HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, pl.W, diag_class_workgroups(ctx, db, wk, c), q,
                                              c == 1 ? ctx->stream2 : s));
@@ -638,12 +653,13 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                        wk.plan[0].workgroups, wk.n_classes);
         for (int c = 0; c < wk.n_classes; ++c) {
             const size_t n = (size_t)wk.plan[c].workgroups * wk.plan[c].W;
-            std::vector<uint64_t> h(n * 3);
-            HIP_TRY(ctx, hipMemcpy(h.data(), d_trace[c], n * 24, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> h(n * 4);
+            HIP_TRY(ctx, hipMemcpy(h.data(), d_trace[c], n * 32, hipMemcpyDeviceToHost));
             (void)hipFree(d_trace[c]);
             for (size_t i = 0; f && i < n; ++i)
-                fprintf(f, "%d %zu %zu %llu %llu %llu\n", c, i / wk.plan[c].W, i % wk.plan[c].W,
-                        (unsigned long long)h[3 * i], (unsigned long long)h[3 * i + 1], (unsigned long long)h[3 * i + 2]);
+                fprintf(f, "%d %zu %zu %llu %llu %llu %llu\n", c, i / wk.plan[c].W, i % wk.plan[c].W,
+                        (unsigned long long)h[4 * i], (unsigned long long)h[4 * i + 1], (unsigned long long)h[4 * i + 2],
+                        (unsigned long long)h[4 * i + 3]);
         }
         if (f) fclose(f);
     }
@@ -729,10 +745,10 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
         int rc = prepare_diag(ctx, db, c);
         if (rc != SWG_OK) return rc;
         double ms_min = 1e300;
-        for (int rep = 0; rep < 2; ++rep) {
+        for (int rep = 0; rep < 3; ++rep) {
             bool two = false;
             HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, ctx->stream));
-            HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, 64, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, SWG_COUNTER_BYTES, ctx->stream));
             rc = launch_diag(ctx, db, c, go, ge, &two);
             if (rc != SWG_OK) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -802,7 +818,7 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
         double ms_min = 1e300;
         for (int rep = 0; rep < 2; ++rep) {
             HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, ctx->stream));
-            HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, 64, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, SWG_COUNTER_BYTES, ctx->stream));
             if ((rc = launch_systolic(ctx, db, pl, go, ge)) != SWG_OK) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             double ms = 0;
@@ -978,7 +994,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[0], s));
     HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, s));
-    HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, 64, s));
+    HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, SWG_COUNTER_BYTES, s));
 
     SwgFillParams p;
     memset(&p, 0, sizeof p);

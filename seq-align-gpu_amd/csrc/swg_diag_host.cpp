@@ -11,6 +11,9 @@
 // Measured on MI355X (profiles/r01_valu_issue_rates.txt): cycles one SIMD needs per
 // packed-int16 / DPP / v_perm wave-instruction when `wps` waves share it.
 static const double kCyclesPerInstr[5] = {0.0, 6.8, 5.3, 5.05, 4.56};
+// ... and per instruction of a raised-priority wavefront beside three others (traced: the long
+// class advances a 4-row block of 64 x 6 columns, 296 instructions, every 1.6 us)
+static const double kHotCycles = 13.0;
 
 uint64_t swg_db_pair_count(const swg_db *db) { return (db->n_local + 1) / 2; }
 
@@ -75,7 +78,7 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
             if (dynamic && npass > 1) continue; // the queue serves single-pass classes only
             const double instr = npass * instr_per_row(info.K, G);
             const double cost = instr / (64 / G);                     // per pair-row
-            const double depth = ((double)longest_rows + G) * instr * 7.5; // raised priority: ~a wave alone
+            const double depth = ((double)longest_rows + G) * instr * kHotCycles;
             SwgDiagPlan c;
             memset(&c, 0, sizeof c);
             c.variant = v;
@@ -189,7 +192,7 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                         const double linstr = instr_per_row(lp.K, lp.G);
                         work += (double)rows_long / (64 / lp.G) * lp.npass * linstr * cps;
                         const double lcrit = (std::max<double>((double)rows_long / lstreams, (double)longest_long) + lp.G) *
-                                             lp.npass * linstr * 7.5;
+                                             lp.npass * linstr * kHotCycles;
                         crit = std::max(crit, lcrit);
                     }
                     double cycles = std::max(work / simds, crit);

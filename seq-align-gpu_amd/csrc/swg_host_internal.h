@@ -30,6 +30,13 @@ struct SwgDiagLayout {
     uint64_t d_scratch_rows = 0;
 };
 
+// Per-search device counters: words [0..15] work queue of the systolic engine, saturated count,
+// re-score queue, top-K; then the sharded pair queues of the diagonal engine's two classes and their
+// per-SIMD wavefront-rank counters.
+#define SWG_QUEUE_WORD(c) (32u + (uint32_t)(c) * SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE)
+#define SWG_RANK_WORD(c) (SWG_QUEUE_WORD(2) + (uint32_t)(c) * SWG_DYN_SIMD_SLOTS)
+#define SWG_COUNTER_BYTES ((size_t)SWG_RANK_WORD(2) * 4u)
+
 // Pair-major tokens for the work-queue form of the diagonal engine: pair p of the sorted
 // order owns blocks [pair_off[p], pair_off[p+1]); independent of the launch geometry.
 struct SwgPairTokens {
@@ -138,7 +145,7 @@ struct swg_ctx {
     // query
     std::vector<int8_t> query;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 1;
     // device state
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;

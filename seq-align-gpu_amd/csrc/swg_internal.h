@@ -51,17 +51,25 @@ struct SwgDiagParams {
     uint64_t *trace;                 // diagnostics (SWG_TRACE): per wavefront {start, end, blocks}, or null
 };
 
-// The same fill with pairs handed out by a device-wide counter (single pass only).
+// The same fill with pairs handed out by device-wide counters (single pass only).
+#define SWG_DYN_SHARDS 8u        // counters per range; shard c hands out pairs begin + c + 8k
+#define SWG_DYN_SHARD_STRIDE 32u // dwords between counters: one 128-byte line each
+#define SWG_DYN_SIMD_SLOTS 8192u // wavefront-rank counters, one per physical SIMD (xcc, se, sh, cu, simd)
 struct SwgDiagDynParams {
     const uint2 *tok;         // pair-major token blocks (4 rows = 8 bytes each), longest pair first
     const uint32_t *pair_off; // [n_pairs+1] block offset of each pair's tokens
-    uint32_t q_begin, q_end;  // this launch serves pairs [q_begin, q_end)
-    uint32_t *queue;          // work counter, zero before the launch
+    uint32_t q_begin, q_end;  // this launch serves pairs [q_begin, q_end) ...
+    uint32_t *queue;          // ... handed out by these SWG_DYN_SHARDS counters (zero before the launch)
+    uint32_t q2_begin, q2_end; // then helps with [q2_begin, q2_end) (empty: none), which another
+    uint32_t *queue2;          // launch is serving off these counters
     const uint8_t *profile;   // [G*K/ch][32][ch] int16
     int32_t *scores;          // by sorted rank: pair p -> 2p, 2p+1
     uint32_t G;
     uint32_t go, ge;          // |gap_open+gap_extend|, |gap_extend| in both halves
     uint32_t prio_blocks;     // a wavefront feeding a pair of >= this many blocks runs at raised priority
+    uint32_t prio_blocks2;    // the same for pairs of the second range
+    uint32_t *simd_ranks;     // [SWG_DYN_SIMD_SLOTS] zero before the launch
+    uint32_t turn_levels;     // priorities the other wavefronts rotate through: 3 beside a long class, else 4
     uint64_t *trace;          // diagnostics (SWG_TRACE) or null
 };
 

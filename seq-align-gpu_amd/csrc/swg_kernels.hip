@@ -440,28 +440,46 @@ template <int K> struct CellsDiag {
         mdl = 0u;
     }
 
-    // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows)
+    // raw profile words of chunk c for both sequences (one LDS read each)
+    struct Raw {
+        uint32_t x[CH / 2], y[CH / 2];
+    };
+    DEVINL Raw load_chunk(const uint8_t *prof, uint32_t offx, uint32_t offy, int c) const
+    {
+        Raw r;
+        if constexpr (CH == 4) {
+            const uint2 wx = *reinterpret_cast<const uint2 *>(prof + offx + c * CHUNK);
+            const uint2 wy = *reinterpret_cast<const uint2 *>(prof + offy + c * CHUNK);
+            r.x[0] = wx.x, r.x[1] = wx.y, r.y[0] = wy.x, r.y[1] = wy.y;
+        } else {
+            r.x[0] = *reinterpret_cast<const uint32_t *>(prof + offx + c * CHUNK);
+            r.y[0] = *reinterpret_cast<const uint32_t *>(prof + offy + c * CHUNK);
+        }
+        return r;
+    }
+
+    // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows).  FENCED: software
+    // pipeline with a depth of one chunk -- chunk c+1's profile reads are issued before chunk c's
+    // arithmetic and nothing moves across the chunk boundary, so at most two chunks' words (8
+    // registers) are in flight.  Left alone the scheduler hoists eight reads and K=24 spills.
+    template <bool FENCED = false>
     DEVINL uint2 row(const uint8_t *prof, uint32_t offx, uint32_t offy, uint32_t em, uint32_t eb,
                      uint32_t go, uint32_t ge)
     {
+        constexpr int NCH = K / CH;
         uint32_t md = mdl;
         uint32_t gl = pk_sub_u16_sat(em, go);
         uint32_t bl = eb;
+        Raw nextw = load_chunk(prof, offx, offy, 0);
 #pragma unroll
-        for (int c = 0; c < K / CH; ++c) {
+        for (int c = 0; c < NCH; ++c) {
+            const Raw w = nextw;
+            if (c + 1 < NCH) nextw = load_chunk(prof, offx, offy, c + 1);
             uint32_t s[CH];
-            if constexpr (CH == 4) {
-                const uint2 wx = *reinterpret_cast<const uint2 *>(prof + offx + c * CHUNK);
-                const uint2 wy = *reinterpret_cast<const uint2 *>(prof + offy + c * CHUNK);
-                s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
-                s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
-                s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
-                s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
-            } else {
-                const uint32_t wx = *reinterpret_cast<const uint32_t *>(prof + offx + c * CHUNK);
-                const uint32_t wy = *reinterpret_cast<const uint32_t *>(prof + offy + c * CHUNK);
-                s[0] = __builtin_amdgcn_perm(wy, wx, 0x05040100u);
-                s[1] = __builtin_amdgcn_perm(wy, wx, 0x07060302u);
+#pragma unroll
+            for (int h = 0; h < CH / 2; ++h) {
+                s[2 * h] = __builtin_amdgcn_perm(w.y[h], w.x[h], 0x05040100u);
+                s[2 * h + 1] = __builtin_amdgcn_perm(w.y[h], w.x[h], 0x07060302u);
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
@@ -477,6 +495,7 @@ template <int K> struct CellsDiag {
                 bl = b;
                 best = pk_max_i16(best, m);
             }
+            if (FENCED && c + 1 < NCH) __builtin_amdgcn_sched_barrier(0);
         }
         mdl = em;
         return make_uint2(M[K - 1], bl);
@@ -623,10 +642,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
         }
     }
     if (p.trace && lane == 0) {
-        uint64_t *t = p.trace + (size_t)(blockIdx.x * W + w) * 3u;
+        uint64_t *t = p.trace + (size_t)(blockIdx.x * W + w) * 4u;
         t[0] = t_start;
         t[1] = wall_clock64();
         t[2] = wave_nblk;
+        t[3] = 0ull;
     }
 }
 
@@ -643,54 +663,167 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 // issue port.  With the queue every resident wavefront stays busy until the
 // pairs are gone, whatever rate it ran at.
 //
-// The leader asks three block-steps ahead (atomic, then the pair's token range,
-// then the switch), so neither round trip is waited for.  The pair ids travel
-// from the leader to the tail lane, which writes the scores, through a small
-// ring in LDS.
-// Per lane group, in LDS after the profile: 32 dwords of bookkeeping that is only touched
-// when a pair starts or ends (keeping it out of the register file is what lets K=24 fit in
-// 128 VGPRs): [0] stage | hot<<2, [1] id of the pair asked for, [2] ids pushed, [3] ids
-// popped, [16..31] ring of pair ids.
+// A lane group's bookkeeping lives in LDS (32 dwords per group, after the
+// profile) and is only touched when one of the wavefront's pairs runs out; between
+// such events a block costs a scalar compare and the leader's token load.  The
+// register file holds the DP state and one token index, which is what lets K=24
+// fit 128 VGPRs without spilling.  When a pair runs out its leader takes the next
+// one there and then (counter, then the pair's token range: two round trips, at
+// raised priority so that a wavefront whose turn it is to yield does not crawl
+// through the bookkeeping); that stalls one wavefront for a few microseconds
+// about once per hundred blocks while the others keep the issue port busy.
+// Pair ids reach the tail lane, which writes the scores, through a ring in the
+// same LDS record.  A launch may name a second range of pairs to go on with when
+// its own is empty: the long class ends early and then helps with the bulk.
+//
+// LDS record of a lane group: [0] value of the wavefront's block counter at which
+// the current pair has no more tokens to load (NONE: no pair and none to come),
+// [1] flags, [2] ids pushed, [3] ids popped, [16..31] ring of pair ids.
+#ifndef SWG_DYN_FENCE_ABOVE
+#define SWG_DYN_FENCE_ABOVE 16 // fence the profile prefetch for K above this
+#endif
 #define SWG_DYN_STATE 32u
 #define SWG_DYN_RING 16u
+#ifndef SWG_DYN_TURN_SHIFT
+#define SWG_DYN_TURN_SHIFT 14 // a turn lasts 2^14 ticks of the 100 MHz clock (164 us): long against a block even for the wavefront whose turn it is to yield
+#endif
+#ifndef SWG_DYN_TURN_EVERY
+#define SWG_DYN_TURN_EVERY 1u // the clock is looked at every block (a stale priority ties with a fresh one, and ties go to the oldest)
+#endif
+#define SWG_DYN_HOT 4u     // current pair is long: raised priority
+#define SWG_DYN_SECOND 8u  // on the second range
+#define SWG_DYN_NONE 0xFFFFFFFFu
+// flags bits 8..: shards of the current range found empty so far
 
 template <int K, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDynParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile, then the group states
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile, then the group records
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int W = (int)(blockDim.x >> 6);
     const int G = (int)p.G;
+    const int gshift = G == 16 ? 4 : G == 32 ? 5 : 6;
     const int g = lane & (G - 1);
     const bool leader = g == 0, tail = g == G - 1;
     constexpr int CH = CellsDiag<K>::CH;
     const uint32_t base = (uint32_t)g * (K / CH) * CellsDiag<K>::CHUNK;
     const uint32_t slice = (uint32_t)G * K * 64u;
     // recomputed where it is needed (rarely) instead of living in a register
-    auto state = [&]() -> uint32_t * {
+    auto record = [&]() -> uint32_t * {
         const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        return reinterpret_cast<uint32_t *>(smem + slice) + ((uint32_t)w * (64u / (uint32_t)G) + l / (uint32_t)G) * SWG_DYN_STATE;
+        return reinterpret_cast<uint32_t *>(smem + slice) + (((uint32_t)w << (6 - gshift)) + (l >> gshift)) * SWG_DYN_STATE;
     };
     const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
     for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
         *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(p.profile + o);
-    if (g < 4) state()[g] = 0u;
+    if (g < 4) record()[g] = 0u; // every group is due at block 0
     __syncthreads();
 
     CellsDiag<K> cells;
     cells.reset();
     uint32_t tok = 0u, m_out = 0u, b_out = 0u, c_out = 0u;
     uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
-    // leader lane: token blocks of the current pair still to load and where the next one is;
-    // t0/t1 hold what the last request returns until the next bookkeeping step picks it up
-    uint32_t left = 0u, bi = 0u, t0 = 0u, t1 = 0u;
-    uint32_t drain = 0u, blocks = 0u;
+    uint32_t bi = SWG_DYN_NONE;  // leader lane: next token block of the pair it feeds (none: idle)
+    // wave-uniform: block counter, the count at which the next pair runs out (none: all leaders idle)
+    uint32_t blocks = 0u, next_event = 0u, drain = 0u, events = 0u;
+    uint64_t event_ticks = 0ull; // diagnostics
     bool hot = false;
-    // wave slot on its SIMD: HW_REG_HW_ID (id 4) bits 3:0
-    const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    // rank of this wavefront among the launch's wavefronts on its SIMD (0, 1, 2 ..): one counter per
+    // physical SIMD, found through HW_REG_HW_ID (id 4: simd 5:4, cu 11:8, sh 12, se 15:13) and
+    // HW_REG_XCC_ID (id 20, bits 3:0).  The wave slot (HW_ID 3:0) would not do: another launch's
+    // wavefronts sit between ours, so our slots are not consecutive.
+    uint32_t rank;
+    {
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((11 << 11) | (4 << 6) | 4);  // bits 15:4
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20); // bits 3:0
+        const uint32_t simd = (((hw >> 4) << 2) | (hw & 3u) | (xcc << 10)) & (SWG_DYN_SIMD_SLOTS - 1u);
+        uint32_t r = 0u;
+        if (lane == 0) r = atomicAdd(p.simd_ranks + simd, 1u);
+        rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    }
+    // The arbiter serves the highest priority first and among equals the oldest wavefront, and
+    // these wavefronts live as long as the kernel: left alone, the youngest of a SIMD would crawl
+    // and the pair it holds would end long after the queue is empty.  Everyone not on the critical
+    // path therefore takes turns at the lower priorities.  The turn comes from the wall clock (the
+    // wavefronts of a SIMD see the same phase) plus the rank, so that at any time they hold
+    // different priorities: rotating on a private counter leaves ties, and ties go to the oldest.
+    auto take_turn = [&]() {
+        const uint32_t phase = (uint32_t)(wall_clock64() >> SWG_DYN_TURN_SHIFT);
+        const uint32_t turn = (phase + rank) % p.turn_levels;
+        if (turn == 0u) __builtin_amdgcn_s_setprio(0);
+        else if (turn == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (turn == 2u) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    };
 
     for (;;) {
+        if (blocks == next_event) {
+            // some pair has run out (or this is the start): its leader takes the next one
+            __builtin_amdgcn_s_setprio(3);
+            const uint64_t ev0 = p.trace ? wall_clock64() : 0ull;
+            ++events;
+            uint32_t *st = record();
+            uint32_t end_at = st[0];
+            uint32_t fl = st[1];
+            if (leader && end_at == blocks) {
+                // The queue is SWG_DYN_SHARDS counters, shard c handing out pairs begin+c, begin+c+S, ..
+                // (one counter for everybody saturates the atomic unit of its memory channel at ~16
+                // requests/us and every request then takes 16 us).  A leader starts at its workgroup's
+                // home shard and moves on when a shard is empty.
+                bool second = (fl & SWG_DYN_SECOND) != 0u;
+                uint32_t tried = fl >> 8;
+                uint32_t nq = SWG_DYN_NONE;
+                for (;;) {
+                    if (tried >= SWG_DYN_SHARDS) {
+                        if (second || p.q2_end <= p.q2_begin) break;
+                        second = true; // own range empty: go on with the other launch's
+                        tried = 0u;
+                    }
+                    const uint32_t shard = (blockIdx.x + tried) & (SWG_DYN_SHARDS - 1u);
+                    uint32_t *ctr = (second ? p.queue2 : p.queue) + shard * SWG_DYN_SHARD_STRIDE;
+                    const uint32_t cand = (second ? p.q2_begin : p.q_begin) + shard + SWG_DYN_SHARDS * atomicAdd(ctr, 1u);
+                    if (cand < (second ? p.q2_end : p.q_end)) {
+                        nq = cand;
+                        break;
+                    }
+                    ++tried;
+                }
+                fl = (second ? SWG_DYN_SECOND : 0u) | (tried << 8);
+                if (nq != SWG_DYN_NONE) {
+                    bi = p.pair_off[nq];
+                    const uint32_t len = p.pair_off[nq + 1u] - bi;
+                    end_at = blocks + len;
+                    const uint32_t pushed = st[2];
+                    st[16u + (pushed & (SWG_DYN_RING - 1u))] = nq;
+                    st[2] = pushed + 1u;
+                    if (len >= (second ? p.prio_blocks2 : p.prio_blocks)) fl |= SWG_DYN_HOT;
+                } else {
+                    end_at = SWG_DYN_NONE;
+                    bi = SWG_DYN_NONE;
+                }
+                st[0] = end_at;
+                st[1] = fl;
+            }
+            next_event = SWG_DYN_NONE;
+            for (int i = 0; i < 64; i += G)
+                next_event = min(next_event, (uint32_t)__builtin_amdgcn_readlane((int)end_at, i));
+            // a wavefront feeding a long pair is on the critical path: it keeps the raised priority
+            hot = __builtin_amdgcn_ballot_w64(leader && end_at != SWG_DYN_NONE && (fl & SWG_DYN_HOT) != 0u) != 0ull;
+            if (!hot) take_turn();
+            if (p.trace) event_ticks += wall_clock64() - ev0;
+        }
+        if (next_event == SWG_DYN_NONE) {
+            // every leader out of pairs: let the rows in flight reach the tail lanes, then leave
+            if (drain >= (uint32_t)G + 12u) break;
+            drain += 4u;
+        }
+        cur = nxt;
+        nxt = make_uint2(0u, 0u);
+        if (bi != SWG_DYN_NONE) {
+            nxt = p.tok[bi];
+            ++bi;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t word = (r & 2) ? cur.y : cur.x;
@@ -728,10 +861,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 go_t |= fm;
                 ge_t |= fm;
             }
-            const uint2 e = cells.row(smem, base + ox, base + oy, em, eb, go_t, ge_t);
+            const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(smem, base + ox, base + oy, em, eb, go_t, ge_t);
             c_out = pk_max_i16(cin, cells.best);
             if (special && tail && (tok & SWG_TOK_LAST)) {
-                uint32_t *st = state();
+                uint32_t *st = record();
                 const uint32_t popped = st[3];
                 const uint32_t pr = st[16u + (popped & (SWG_DYN_RING - 1u))];
                 st[3] = popped + 1u;
@@ -742,70 +875,15 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             b_out = e.y;
         }
         ++blocks;
-        // The arbiter serves the oldest wavefront of a SIMD first, and these wavefronts live as long
-        // as the kernel: left alone, the youngest would crawl and the pair it holds would end long
-        // after the queue is empty.  Everyone not on the critical path therefore cycles through the
-        // lower priorities, offset by its wave slot, and gets the same share over time.
-        if (!hot && (blocks & 3u) == 0u) {
-            const uint32_t turn = ((blocks >> 2) + slot) % 3u;
-            if (turn == 0u) __builtin_amdgcn_s_setprio(0);
-            else if (turn == 1u) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(2);
-        }
-        cur = nxt;
-        nxt = make_uint2(0u, 0u);
-        const bool low = leader && left <= 3u;
-        if (__builtin_amdgcn_ballot_w64(low) != 0ull) {
-            uint32_t *st = state();
-            uint32_t sf = st[0];
-            if (low) {
-                const uint32_t stage = sf & 3u;
-                if (stage == 2u && left == 0u) {
-                    const uint32_t nq = st[1];
-                    if (nq < p.q_end) { // the pair asked for becomes the one being fed
-                        bi = t0;
-                        left = t1 - t0;
-                        const uint32_t pushed = st[2];
-                        st[16u + (pushed & (SWG_DYN_RING - 1u))] = nq;
-                        st[2] = pushed + 1u;
-                        sf = left >= p.prio_blocks ? 4u : 0u;
-                    } else {
-                        sf = 3u;
-                    }
-                } else if (stage == 1u) {
-                    const uint32_t nq = t0;
-                    st[1] = nq;
-                    if (nq < p.q_end) {
-                        t0 = p.pair_off[nq];
-                        t1 = p.pair_off[nq + 1u];
-                    }
-                    sf = (sf & 4u) | 2u;
-                } else if (stage == 0u) {
-                    t0 = p.q_begin + atomicAdd(p.queue, 1u);
-                    sf = (sf & 4u) | 1u;
-                }
-                st[0] = sf;
-            }
-            // a wavefront feeding a long pair is on the critical path: issue priority over its neighbours
-            hot = __builtin_amdgcn_ballot_w64(leader && (sf & 4u) != 0u) != 0ull;
-            if (hot) __builtin_amdgcn_s_setprio(3);
-            // every leader out of pairs: let the rows in flight reach the tail lanes, then leave
-            if (__builtin_amdgcn_ballot_w64(leader && (sf & 3u) != 3u) == 0ull) {
-                drain += 4u;
-                if (drain >= (uint32_t)G + 12u) break;
-            }
-        }
-        if (leader && left > 0u) {
-            nxt = p.tok[bi];
-            ++bi;
-            --left;
-        }
+        if (!hot && (blocks & (SWG_DYN_TURN_EVERY - 1u)) == 0u) take_turn();
     }
     if (p.trace && lane == 0) {
-        uint64_t *t = p.trace + (size_t)(blockIdx.x * W + w) * 3u;
+        uint64_t *t = p.trace + (size_t)(blockIdx.x * W + w) * 4u;
         t[0] = t_start;
         t[1] = wall_clock64();
-        t[2] = blocks;
+        t[2] = (uint64_t)blocks | ((uint64_t)events << 32) | (event_ticks << 44);
+        t[3] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) | ((uint64_t)rank << 32) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 40);
     }
 }
 

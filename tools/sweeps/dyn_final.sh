@@ -9,10 +9,17 @@ print('$*', '->', d['value'],'GCUPS', c['engine'], 'K',c['cols_per_wave'],'G',c.
 }
 run
 run --no-autotune
-run --config 1
+run --no-autotune --no-long-helps
+run --no-autotune --long-split 1200
+run --no-autotune --long-split 1400
+run --no-autotune --long-split 1400 --no-long-helps
+run --no-autotune --long-split 1700
+run --no-autotune --long-split 2000
+run --no-autotune --prio-share 100
+run --no-autotune --prio-share 100000
 run --config 3
-run --config 3 --engine 2
-run --config 5 --steps 5
+run --config 1
 run --nseq 20000
 run --nseq 400000 --lq 200
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+run --config 5 --steps 5
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3

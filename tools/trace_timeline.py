@@ -15,8 +15,12 @@ def main(path, buckets=28):
         elif cur is not None:
             cur["rows"].append([int(x) for x in line.split()])
     f = fills[-1]
-    a = np.array(f["rows"], dtype=np.int64)
+    a = np.array(f["rows"], dtype=np.uint64).astype(np.int64)
     a = a[a[:, 4] > 0]
+    packed = a[:, 5].copy()
+    a[:, 5] = packed & 0xFFFFFFFF            # blocks
+    events = (packed >> 32) & 0xFFF          # work-queue events of the wavefront
+    ev_us = (packed >> 44) / 100.0           # time spent in them
     t0 = a[:, 3].min()
     start = (a[:, 3] - t0) / 100.0  # microseconds (100 MHz ticks)
     end = (a[:, 4] - t0) / 100.0
@@ -31,6 +35,10 @@ def main(path, buckets=28):
         dur = e - s
         rate = dur / np.maximum(nb, 1)
         print("         us per block of 4 rows: p10 %.3f p50 %.3f p90 %.3f" % tuple(np.percentile(rate, [10, 50, 90])))
+        if events[m].max() > 0:
+            print("         queue events per wave: med %d max %d; us in events per wave: p50 %.1f p90 %.1f max %.1f; us per event p50 %.2f"
+                  % (np.median(events[m]), events[m].max(), *np.percentile(ev_us[m], [50, 90]), ev_us[m].max(),
+                     np.median(ev_us[m] / np.maximum(events[m], 1))))
     edges = np.linspace(0, total, buckets + 1)
     print("active waves per time bucket (%.0f us each):" % (total / buckets))
     for c in np.unique(a[:, 0]):
