@@ -102,7 +102,11 @@ int swg_abi_version(void);
  * "long_split" (-1 off | 0 auto | rows above which a pair joins the long class),
  * "autotune" (1 default: on the first search of a query length the few geometries the cost model
  * ranks best are timed on the device and the fastest is kept for that database | 0 model only),
- * "workgroups" (0 auto). */
+ * "workgroups" (0 auto), "work_queue" (1 default: single-pass diagonal fills hand pairs to lane
+ * groups through device-wide counters | 0 fixed streams laid out on the host), "long_helps"
+ * (1 default: lane groups of the long class go on with the bulk's pairs when their own are done),
+ * "prio_share" (percent of a lane group's mean share above which a bulk pair runs at raised
+ * priority; default 150). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 
 /* Replaces scoring_t for the path (reference src/alignment_scoring.h:21-37):

@@ -16,11 +16,14 @@ def _setup(ctx, g):
 
 
 OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups")
+DEFAULT_ON = ("work_queue", "long_helps")
 
 
 def _reset_options(ctx):
     for k in OPTIONS:
         ctx.set_option(k, 0)
+    for k in DEFAULT_ON:
+        ctx.set_option(k, 1)
 
 
 def _truth(g):
@@ -393,6 +396,46 @@ def test_long_tail_database(swg, ctx, orc):
         assert np.array_equal(got, want), (opts, st)
         assert hits == orc.topk(want, 5)
         db.close()
+    _reset_options(ctx)
+
+
+def test_work_queue_variants_agree(swg, ctx, orc):
+    """The diagonal engine with pairs off the work queue (default), with the long class going on
+    with the bulk's pairs or not, and with static streams: same scores.  The database mixes very
+    short sequences (pairs of one or two token blocks, shorter than a lane group is wide), a long
+    tail, and fewer / more pairs than lane groups and queue shards."""
+    sc = swg.load_scoring("PAM250")
+    rng = np.random.default_rng(21)
+    q = swg.synth_query(8, 367)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    shapes = {
+        "tiny": [1, 2, 3],                                           # 2 pairs: most queue shards empty
+        "short": [int(v) for v in rng.integers(1, 12, size=3000)],   # pairs far shorter than 16..64 rows
+        "mixed": [4000, 2500, 1, 1, 2] + [int(v) for v in rng.integers(5, 700, size=6000)],
+    }
+    for name, lens in shapes.items():
+        seqs = [swg.synth_query(1000 + i, L) for i, L in enumerate(lens)]
+        flat = np.concatenate(seqs)
+        off = np.zeros(len(lens) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+        for opts in ({}, {"work_queue": 0}, {"long_helps": 0}, {"long_split": 300}, {"long_split": 300, "long_helps": 0},
+                     {"long_split": -1}, {"cols_per_wave": 6, "group_lanes": 64, "max_waves": 4},
+                     {"cols_per_wave": 12, "group_lanes": 32, "max_waves": 8, "long_split": 500},
+                     {"cols_per_wave": 24, "group_lanes": 16, "max_waves": 4, "workgroups": 3}):
+            _reset_options(ctx)
+            ctx.set_option("engine", 2)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            db = swg.Database(flat, off).upload(ctx)
+            got, hits, st = ctx.search(db, k=7)
+            assert np.array_equal(got, want), (name, opts, st)
+            assert hits == orc.topk(want, 7)
+            # a second search on the same resident database re-arms the queue counters
+            got2, _, _ = ctx.search(db, k=0)
+            assert np.array_equal(got2, want), (name, opts, "second search")
+            db.close()
     _reset_options(ctx)
 
 

@@ -1,3 +1,5 @@
+# A/B of library builds on one box: VARIANTS="prev new" [EXTRA="bench flags"] bash tools/sweeps/ab.sh
+# (libswg_<name>.so next to libswg.so; "new" is the built library)
 cd $GRAFT_REPO_ROOT
 run() {
   timeout -k 20 400 python bench.py --steps ${STEPS:-30} --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | grep '^{' | python -c "
@@ -10,6 +12,6 @@ print('$*', '->', d['value'],'GCUPS', c['engine'], 'K',c['cols_per_wave'],'G',c.
 cp seq-align-gpu_amd/libswg.so /tmp/new.so
 for v in ${VARIANTS}; do
   if [ $v = new ]; then cp /tmp/new.so seq-align-gpu_amd/libswg.so; else cp seq-align-gpu_amd/libswg_$v.so seq-align-gpu_amd/libswg.so; fi
-  echo "== $v"; run --no-autotune ${EXTRA}; run --no-autotune ${EXTRA}
+  echo "== $v"; run --no-autotune ${EXTRA}; run --no-autotune ${EXTRA}; run --no-autotune --config 3
 done
 cp /tmp/new.so seq-align-gpu_amd/libswg.so
