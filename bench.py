@@ -225,12 +225,14 @@ def main():
                 "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
                 "streams": last["streams"], "long_pairs": last["long_pairs"],
                 "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],
+                "work_queue": bool(last["work_queue"]),
                 "cells_padded_over_real": round(last["cells_padded"] / max(1, last["cells"]), 4),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": ("swg_diag_kernel<%d>" % last["cols_per_wave"]) if last["engine"] == 2
+                "kernel": (("swg_diag_dyn_kernel<%d>" if last["work_queue"] else "swg_diag_kernel<%d>") % last["cols_per_wave"])
+                if last["engine"] == 2
                 else "swg_fill_kernel<CellsI%d>" % last["path_bits"], "kernel_ms": round(k_ms, 4),
                 "bytes_alg_per_launch": bytes_alg,
                 "binding_roof": {"bound": "valu_issue", "kernel_gcups": round(kernel_gcups, 2),

@@ -81,7 +81,7 @@ typedef struct swg_stats {
     int32_t long_pairs;     /* diagonal engine: longest pairs run as their own class, 64 lanes each */
     int32_t long_cols_per_lane;
     int32_t long_streams;
-    int32_t reserved;
+    int32_t work_queue;     /* diagonal engine: 1 = pairs handed out by the device-side work queue */
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */

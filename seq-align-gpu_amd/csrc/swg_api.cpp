@@ -741,29 +741,35 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
     }
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     double best_ms = 1e300;
+    // One trial = a warm-up fill, then four fills queued back to back the way consecutive searches
+    // are, timed as a whole: what happens where one fill ends and the next begins (workgroups of
+    // two classes competing for the freed slots) is part of what is being chosen.
     auto time_one = [&](const SwgDiagWork &c, double *ms_out) -> int {
         int rc = prepare_diag(ctx, db, c);
         if (rc != SWG_OK) return rc;
-        double ms_min = 1e300;
-        for (int rep = 0; rep < 3; ++rep) {
+        const int reps = 4;
+        for (int rep = -1; rep < reps; ++rep) {
             bool two = false;
+            if (rep == 0) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[0], ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, SWG_COUNTER_BYTES, ctx->stream));
             rc = launch_diag(ctx, db, c, go, ge, &two);
             if (rc != SWG_OK) return rc;
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            double ms = 0;
-            if ((rc = diag_fill_ms(ctx, two, &ms)) != SWG_OK) return rc;
-            ms_min = std::min(ms_min, ms);
         }
-        *ms_out = ms_min;
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[4], ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[0], ctx->cur->ev[4]));
+        *ms_out = (double)ms / reps;
         return SWG_OK;
     };
     for (const SwgDiagWork &c : pick) {
         double ms = 0;
         int rc = time_one(c, &ms);
         if (rc != SWG_OK) return rc;
-        if (ms < best_ms) {
+        // the model's first choice stays unless another geometry is clearly (1.5 %) faster: two
+        // timings of the same fill differ by about a percent
+        if (ms < best_ms * (best_ms < 1e299 ? 0.985 : 1.0)) {
             best_ms = ms;
             *best = c;
             best->plan[0].est_ms = ms;
@@ -795,7 +801,7 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
             double ms = 0;
             int rc = time_one(*same, &ms);
             if (rc != SWG_OK) return rc;
-            if (ms < best_ms) {
+            if (ms < best_ms * 0.985) {
                 best_ms = ms;
                 *best = *same;
                 best->plan[0].est_ms = ms;
@@ -1163,6 +1169,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         st.waves = dpl.W;
         st.passes = dpl.npass;
         st.workgroups = diag_class_workgroups(ctx, db, wk, 0);
+        st.work_queue = diag_class_is_dynamic(ctx, db, dpl) ? 1 : 0;
         st.streams = (int32_t)diag_class_streams(ctx, db, wk, 0);
         st.cells_padded = 2ull * dpl.npass * dpl.G * dpl.K * diag_class_blocks(ctx, db, wk, 0) * 4ull;
         if (wk.n_classes == 2) {

@@ -133,6 +133,10 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                 const int W = 4 * wps;
                 if (W > info.max_waves) continue;
                 if (opt_waves > 0 && W != (int)opt_waves) continue;
+                // with the work queue the workgroup size does not matter for balance; four wavefronts
+                // (one per SIMD) interleave the two classes on every CU, larger workgroups partition the
+                // CUs between them (timed faster in isolation, slower back to back)
+                if (dynamic && opt_waves == 0 && wps != 1) continue;
                 const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)));
                 const int eff_wps = std::min(4, wps * per_cu);
                 const double cps = kCyclesPerInstr[eff_wps];

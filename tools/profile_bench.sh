@@ -24,6 +24,15 @@ for d in ("fetch", "write", "sq", "lds"):
             ctr[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary["pmc_mean_per_launch"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in ctr.items()}
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
+# HBM traffic of one search: the fill kernels' FETCH_SIZE (doubled: gfx950 reports half of the fetched
+# bytes, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes, mean per launch
+fill = {k: cs for k, cs in summary["pmc_mean_per_launch"].items() if ("diag" in k or "fill_kernel" in k) and "FETCH_SIZE" in cs}
+fetch = sum(cs["FETCH_SIZE"] for cs in fill.values()); write = sum(cs.get("WRITE_SIZE", 0.0) for cs in fill.values())
+json.dump({"config$CFG": {"hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh), mean per launch, summed over the fill kernels of one search; KiB -> bytes; FETCH_SIZE doubled (gfx950 correction of the guide's HBM section)",
+           "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+           "kernels": {k: {"FETCH_SIZE": cs["FETCH_SIZE"], "WRITE_SIZE": cs.get("WRITE_SIZE", 0.0)} for k, cs in fill.items()}}},
+          open(out + "/traffic.json", "w"), indent=1)
 for k, cs in summary["pmc_mean_per_launch"].items():
     if "diag" in k or "fill" in k:
         print(k, {c: "%.4g" % v for c, v in cs.items()})

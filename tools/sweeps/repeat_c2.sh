@@ -4,9 +4,11 @@ run() {
 import sys,json
 d=json.loads(sys.stdin.read())
 c=d['config']
-print('$*', '->', d['value'],'GCUPS K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'long',c.get('long_pairs'),c.get('long_cols_per_lane'),'pad', c['cells_padded_over_real'], 'step', d['ms_per_step'], d['kernel_ms'])
+print('$*', '->', d['value'],'GCUPS', c['engine'], 'K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'wgs',c['workgroups'], 'long',c.get('long_pairs'),c.get('long_cols_per_lane'),c.get('long_streams'),'pad', c['cells_padded_over_real'], 'step', d['ms_per_step'], 'fill', d['kernel_ms']['fill'])
 "
 }
-timeout -k 10 300 python -m pytest tests -m gpu -x -q -k "golden_through_search or device_topk or rescore" 2>&1 | tail -2
-for i in 1 2 3 4 5 6; do run --config 2; done
+for i in 1 2 3 4 5; do run; done
+run --no-autotune
 run --config 3
+run --nseq 400000 --lq 200
+run --nseq 20000
