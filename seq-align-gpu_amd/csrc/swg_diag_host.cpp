@@ -201,6 +201,9 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     }
                     double cycles = std::max(work / simds, crit);
                     cycles *= 1.0 + 0.04 * (npass - 1); // profile reloads, pass barriers, edge spills
+                    // fixed streams lose what the work queue was built to recover (uneven wavefront
+                    // rates, a thinning tail): measured 4 900 against 5 600 GCUPS on config 2
+                    if (!dynamic) cycles *= 1.15;
                     const double ms = cycles / 2.35e9 * 1e3;
                     {
                         SwgDiagWork one;

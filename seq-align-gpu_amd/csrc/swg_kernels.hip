@@ -613,7 +613,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                     go_t |= fm;
                     ge_t |= fm;
                 }
-                const uint2 e = cells.row(smem, base + ox, base + oy, em, eb, go_t, ge_t);
+                const uint2 e = cells.template row<(K > 16)>(smem, base + ox, base + oy, em, eb, go_t, ge_t);
                 c_out = pk_max_i16(cin, cells.best);
                 if (special && tail && (tok & SWG_TOK_LAST)) {
                     const uint32_t pr = p.stream_pairs[pair0 + done];
@@ -1236,7 +1236,8 @@ const DiagVariant *diag_variants(int *n)
 {
     static const DiagVariant v[] = {
         make_diag<24, 16>(), make_diag<12, 16>(), make_diag<8, 16>(), make_diag<16, 16>(), make_diag<32, 12>(),
-        make_diag<6, 16>(),  make_diag<10, 16>(),
+        make_diag<6, 16>(),  make_diag<10, 16>(), make_diag<20, 16>(), make_diag<28, 12>(), make_diag<4, 16>(),
+        make_diag<14, 16>(), make_diag<18, 16>(), make_diag<22, 16>(),
     };
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
