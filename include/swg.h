@@ -106,7 +106,9 @@ int swg_abi_version(void);
  * groups through device-wide counters | 0 fixed streams laid out on the host), "long_helps"
  * (1 default: lane groups of the long class go on with the bulk's pairs when their own are done),
  * "prio_share" (percent of a lane group's mean share above which a bulk pair runs at raised
- * priority; default 150). */
+ * priority; default 150), "wide16" (1 default: when the query is long enough for a score to pass
+ * 32767 the diagonal engine runs its wide form, exact to 65535, and only scores beyond that are
+ * re-scored in int32 | 0: plain int16 and int32 re-score from 32767). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 
 /* Replaces scoring_t for the path (reference src/alignment_scoring.h:21-37):

@@ -176,6 +176,8 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         g_swg_long_group = value;
     } else if (!strcmp(key, "autotune")) {
         ctx->opt_autotune = value != 0;
+    } else if (!strcmp(key, "wide16")) {
+        ctx->opt_wide = value != 0;
     } else if (!strcmp(key, "long_helps")) {
         ctx->opt_long_helps = value != 0;
     } else if (!strcmp(key, "work_queue")) {
@@ -477,7 +479,7 @@ static int ensure_pair_tokens(swg_ctx *ctx, swg_db *db)
 // (a pair's edge spill has to be read back by the lane group that wrote it).
 static bool diag_class_is_dynamic(const swg_ctx *ctx, const swg_db *db, const SwgDiagPlan &pl)
 {
-    return pl.npass == 1 && ctx->opt_dynamic != 0 && db->ptok.ok;
+    return pl.npass == 1 && !pl.wide && ctx->opt_dynamic != 0 && db->ptok.ok;
 }
 
 // Workgroups to launch for class c.  Work-queue kernels are persistent: a workgroup that is not
@@ -635,7 +637,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                         : (double)L.max_stream_blocks > 1.1 * mean_blocks ? (uint32_t)(0.75 * (double)L.max_stream_blocks)
                                                                           : 0xFFFFFFFFu;
         d.trace = d_trace[c];
-        HIP_TRY(ctx, swg_launch_diag(pl.variant, pl.npass > 1, pl.W, pl.workgroups, pl.lds_bytes, d,
+        HIP_TRY(ctx, swg_launch_diag(pl.variant, pl.npass > 1, pl.wide != 0, pl.W, pl.workgroups, pl.lds_bytes, d,
                                      c == 1 ? ctx->stream2 : s));
     }
     if (wk.n_classes == 2) {
@@ -907,6 +909,23 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         return swg_set_ctx_error(ctx, SWG_ERR_ARG,
                                  "force_bits=16 needs gap_open <= 0 and gap_extend <= 0");
 
+    // How high can a score get?  Not above the query's best possible total (every column paired
+    // with its best-scoring residue) nor above the longest sequence times the largest table entry.
+    // Below 32767 nothing can saturate; below 65535 the wide form of the diagonal engine (values
+    // biased by -32768, same instruction count) is exact and nothing needs the int32 re-score.
+    int smax = 0;
+    uint64_t qbound = 0;
+    for (int a = 0; a < 32; ++a)
+        for (int b = 0; b < 32; ++b) smax = std::max<int>(smax, ctx->sub[a][b]);
+    for (size_t i = 0; i < lq; ++i) {
+        int best = 0;
+        for (int b = 1; b < 32; ++b) best = std::max<int>(best, ctx->sub[(uint8_t)ctx->query[i] & 31][b]);
+        qbound += (uint64_t)best;
+    }
+    const uint64_t longest = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK;
+    const uint64_t score_bound = std::min<uint64_t>(qbound, std::min<uint64_t>(lq, longest) * (uint64_t)smax);
+    bool wide = bits == 16 && score_bound >= 32767ull && ctx->opt_engine != 1 && ctx->opt_wide != 0;
+
     Plan main_pl, re_pl;
     memset(&main_pl, 0, sizeof main_pl);
     memset(&re_pl, 0, sizeof re_pl);
@@ -915,7 +934,16 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // int16: the diagonal engine unless the systolic one is asked for
     SwgDiagWork wk;
     bool use_diag = false, tuned_systolic = false;
-    if (bits == 16 && ctx->opt_engine != 1) {
+    if (wide) {
+        // wide form: fixed streams (its kernel is the multi-pass one), model-chosen geometry
+        use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
+                                      ctx->opt_long_split, ctx->opt_workgroups == 0, false, &wk) > 0;
+        if (use_diag)
+            for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].wide = 1;
+        else
+            wide = false; // no geometry: the plain form and the int32 re-score
+    }
+    if (bits == 16 && ctx->opt_engine != 1 && !wide) {
         if (ctx->opt_dynamic && (rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
         const bool free_geometry = ctx->opt_cols == 0 && ctx->opt_group == 0 && ctx->opt_max_waves == 0 &&
                                    ctx->opt_long_split == 0 && ctx->opt_workgroups == 0;
@@ -956,12 +984,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         if (!use_diag && !tuned_systolic && rc != SWG_OK) return rc;
     }
     const SwgDiagPlan &dpl = wk.plan[0];
-    // can an int16 score saturate at all?  score <= min(lq, longest) * max(S)
-    int smax = 0;
-    for (int a = 0; a < 32; ++a)
-        for (int b = 0; b < 32; ++b) smax = std::max<int>(smax, ctx->sub[a][b]);
-    const uint64_t longest = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK;
-    const bool may_saturate = bits == 16 && std::min<uint64_t>(lq, longest) * (uint64_t)smax >= 32767ull;
+    const bool may_saturate = bits == 16 && score_bound >= (wide ? 65535ull : 32767ull);
     if (may_saturate) {
         const long keep_cols = ctx->opt_cols;
         ctx->opt_cols = 0; // the int32 re-score uses its default geometry
@@ -1046,7 +1069,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
     if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
     if (may_saturate) {
-        HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, db->d_list,
+        HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, wide ? 65535 : 32767, db->d_list,
                                                   db->d_counters + 1, s));
         p.profile = ctx->d_profile[1];
         p.queue = db->d_counters + 2;

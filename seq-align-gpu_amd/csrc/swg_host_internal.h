@@ -49,6 +49,7 @@ struct SwgPairTokens {
 
 struct SwgDiagPlan {
     int variant, K, G, npass, W, workgroups;
+    int wide; // scores to 65535 (values biased by -32768): fixed streams, multi-pass kernel
     uint32_t n_streams;
     size_t lds_bytes;
     double est_ms;
@@ -145,7 +146,7 @@ struct swg_ctx {
     // query
     std::vector<int8_t> query;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 1;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 1, opt_wide = 1;
     // device state
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;

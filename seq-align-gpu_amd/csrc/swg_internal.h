@@ -97,7 +97,7 @@ hipError_t swg_launch_diag32(int W, int workgroups, const SwgFillParams &p, hipS
 
 int swg_num_diag_variants();
 SwgKernelInfo swg_diag_variant_info(int variant); // K, max_waves (wave budget of one CU)
-hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, size_t lds_bytes,
+hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int workgroups, size_t lds_bytes,
                            const SwgDiagParams &p, hipStream_t stream);
 size_t swg_diag_dyn_lds_bytes(int K, int G, int W);
 hipError_t swg_launch_diag_dyn(int variant, int W, int workgroups, const SwgDiagDynParams &p, hipStream_t stream);
@@ -109,8 +109,8 @@ hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
                                     uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols,
                                     uint8_t *d_profile, hipStream_t stream);
 
-// Appends every slot id whose int16 score saturated (== 32767) to list.
-hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots,
+// Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, or 65535 in the wide form) to list.
+hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling,
                                         uint32_t *d_list, uint32_t *d_count,
                                         hipStream_t stream);
 

@@ -70,6 +70,11 @@ DEVINL uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a),
                                                                       __builtin_bit_cast(u16x2, b)));
 }
+DEVINL uint32_t pk_sub_i16_sat(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a),
+                                                                      __builtin_bit_cast(s16x2, b)));
+}
 DEVINL uint32_t pk_max_i16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a),
@@ -424,7 +429,15 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 #define DPP_ROW_SHR1 0x111
 #define DPP_WAVE_SHR1 0x138
 
-template <int K> struct CellsDiag {
+// WIDE: the same recurrence on values biased by -32768 (a score v is held as v - 32768), which
+// doubles the range to 65535 at the same instruction count: the signed saturating subtract floors
+// at -32768 = score 0, the signed saturating add sticks at 32767 = score 65535, signed max keeps
+// the order.  Used when the query is long enough for a score to pass 32767 (the reference's int16
+// lanes wrap there).  Reset rows cannot use the all-ones gap trick in this form and
+// wipe the state explicitly.
+template <int K, bool WIDE = false> struct CellsDiag {
+    static constexpr uint32_t ZERO = WIDE ? 0x80008000u : 0u;
+    DEVINL static uint32_t sub(uint32_t a, uint32_t b) { return WIDE ? pk_sub_i16_sat(a, b) : pk_sub_u16_sat(a, b); }
     // columns per profile chunk: 4 (one ds_read_b64 per sequence) when K allows it, else 2
     // (ds_read_b32); a chunk is [32 residues][CH] int16
     static constexpr int CH = (K % 4 == 0) ? 4 : 2;
@@ -435,9 +448,22 @@ template <int K> struct CellsDiag {
     DEVINL void reset()
     {
 #pragma unroll
-        for (int k = 0; k < K; ++k) M[k] = G[k] = A[k] = 0u;
-        best = 0u;
-        mdl = 0u;
+        for (int k = 0; k < K; ++k) M[k] = G[k] = A[k] = ZERO;
+        best = ZERO;
+        mdl = ZERO;
+    }
+
+    // lanes with fm = all ones forget everything (WIDE form of a reset row)
+    DEVINL void wipe(uint32_t fm)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            M[k] = (M[k] & ~fm) | (ZERO & fm);
+            G[k] = (G[k] & ~fm) | (ZERO & fm);
+            A[k] = (A[k] & ~fm) | (ZERO & fm);
+        }
+        best = (best & ~fm) | (ZERO & fm);
+        mdl = (mdl & ~fm) | (ZERO & fm);
     }
 
     // raw profile words of chunk c for both sequences (one LDS read each)
@@ -468,7 +494,7 @@ template <int K> struct CellsDiag {
     {
         constexpr int NCH = K / CH;
         uint32_t md = mdl;
-        uint32_t gl = pk_sub_u16_sat(em, go);
+        uint32_t gl = sub(em, go);
         uint32_t bl = eb;
         Raw nextw = load_chunk(prof, offx, offy, 0);
 #pragma unroll
@@ -486,12 +512,12 @@ template <int K> struct CellsDiag {
                 const int k = CH * c + u;
                 const uint32_t t = pk_add_i16_sat(md, s[u]);
                 md = M[k];
-                const uint32_t a = pk_max_i16(G[k], pk_sub_u16_sat(A[k], ge));
-                const uint32_t b = pk_max_i16(gl, pk_sub_u16_sat(bl, ge));
+                const uint32_t a = pk_max_i16(G[k], sub(A[k], ge));
+                const uint32_t b = pk_max_i16(gl, sub(bl, ge));
                 const uint32_t m = pk_max_i16(pk_max_i16(t, a), b);
                 M[k] = m;
                 A[k] = a;
-                gl = G[k] = pk_sub_u16_sat(m, go);
+                gl = G[k] = sub(m, go);
                 bl = b;
                 best = pk_max_i16(best, m);
             }
@@ -514,7 +540,7 @@ template <int CTRL> DEVINL uint32_t dpp_keep(uint32_t keep, uint32_t src)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)keep, (int)src, CTRL, 0xf, 0xf, false);
 }
 
-template <int K, int MAXW, bool MULTIPASS>
+template <int K, int MAXW, bool MULTIPASS, bool WIDE = false>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile of this pass
@@ -556,17 +582,18 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
         }
         __syncthreads();
 
-        CellsDiag<K> cells;
+        constexpr uint32_t Z = CellsDiag<K, WIDE>::ZERO; // score 0 in the cells' representation
+        CellsDiag<K, WIDE> cells;
         cells.reset();
-        uint32_t tok = 0u, m_out = 0u, b_out = 0u, c_out = 0u, done = 0u;
+        uint32_t tok = 0u, m_out = Z, b_out = Z, c_out = Z, done = 0u;
         uint2 cur = (leader && nblk > 0u) ? tp[0] : make_uint2(0u, 0u);
         uint2 nxt = (leader && nblk > 1u) ? tp[1] : make_uint2(0u, 0u);
         uint2 spc[4], spn[4];
         if (MULTIPASS) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                spc[r] = (leader && pass > 0 && (uint32_t)r < rows) ? load_edge_l2(sp + r) : make_uint2(0u, 0u);
-                spn[r] = (leader && pass > 0 && 4u + r < rows) ? load_edge_l2(sp + 4 + r) : make_uint2(0u, 0u);
+                spc[r] = (leader && pass > 0 && (uint32_t)r < rows) ? load_edge_l2(sp + r) : make_uint2(Z, Z);
+                spn[r] = (leader && pass > 0 && 4u + r < rows) ? load_edge_l2(sp + 4 + r) : make_uint2(Z, Z);
             }
         }
 
@@ -575,23 +602,23 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
             for (int r = 0; r < 4; ++r) {
                 const uint32_t word = (r & 2) ? cur.y : cur.x;
                 const uint32_t fresh = (r & 1) ? (word >> 16) : (word & 0xFFFFu);
-                const uint32_t lm = MULTIPASS ? spc[r].x : 0u, lb = MULTIPASS ? spc[r].y : 0u;
+                const uint32_t lm = MULTIPASS ? spc[r].x : Z, lb = MULTIPASS ? spc[r].y : Z;
                 uint32_t em, eb, cin;
                 if (G == 16) {
                     tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
                     em = MULTIPASS ? dpp_keep<DPP_ROW_SHR1>(lm, m_out) : dpp_zero<DPP_ROW_SHR1>(m_out);
                     eb = MULTIPASS ? dpp_keep<DPP_ROW_SHR1>(lb, b_out) : dpp_zero<DPP_ROW_SHR1>(b_out);
-                    cin = dpp_zero<DPP_ROW_SHR1>(c_out);
+                    cin = WIDE ? dpp_keep<DPP_ROW_SHR1>(Z, c_out) : dpp_zero<DPP_ROW_SHR1>(c_out);
                 } else {
                     const uint32_t t0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
                     const uint32_t t1 = MULTIPASS ? dpp_keep<DPP_WAVE_SHR1>(lm, m_out) : dpp_zero<DPP_WAVE_SHR1>(m_out);
                     const uint32_t t2 = MULTIPASS ? dpp_keep<DPP_WAVE_SHR1>(lb, b_out) : dpp_zero<DPP_WAVE_SHR1>(b_out);
-                    const uint32_t t3 = dpp_zero<DPP_WAVE_SHR1>(c_out);
+                    const uint32_t t3 = WIDE ? dpp_keep<DPP_WAVE_SHR1>(Z, c_out) : dpp_zero<DPP_WAVE_SHR1>(c_out);
                     if (G == 32) { // lane 32 starts a group too
                         tok = leader ? fresh : t0;
                         em = leader ? lm : t1;
                         eb = leader ? lb : t2;
-                        cin = leader ? 0u : t3;
+                        cin = leader ? Z : t3;
                     } else {
                         tok = t0;
                         em = t1;
@@ -609,16 +636,20 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                 if (special) {
                     // reset rows: gap magnitudes of all ones wipe A/G/B, two such rows wipe M
                     const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
-                    cells.best &= ~fm;
-                    go_t |= fm;
-                    ge_t |= fm;
+                    if (WIDE) {
+                        cells.wipe(fm);
+                    } else {
+                        cells.best &= ~fm;
+                        go_t |= fm;
+                        ge_t |= fm;
+                    }
                 }
                 const uint2 e = cells.template row<(K > 16)>(smem, base + ox, base + oy, em, eb, go_t, ge_t);
                 c_out = pk_max_i16(cin, cells.best);
                 if (special && tail && (tok & SWG_TOK_LAST)) {
                     const uint32_t pr = p.stream_pairs[pair0 + done];
-                    atomicMax(p.scores + 2u * pr, (int)(c_out & 0xFFFFu));
-                    atomicMax(p.scores + 2u * pr + 1u, (int)(c_out >> 16));
+                    atomicMax(p.scores + 2u * pr, (int)((c_out ^ Z) & 0xFFFFu));
+                    atomicMax(p.scores + 2u * pr + 1u, (int)((c_out ^ Z) >> 16));
                     ++done;
                 }
                 m_out = e.x;
@@ -636,7 +667,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                 for (int r = 0; r < 4; ++r) {
                     spc[r] = spn[r];
                     const uint32_t row = (bi)*4u + (uint32_t)r;
-                    spn[r] = (leader && pass > 0 && row < rows) ? load_edge_l2(sp + row) : make_uint2(0u, 0u);
+                    spn[r] = (leader && pass > 0 && row < rows) ? load_edge_l2(sp + row) : make_uint2(Z, Z);
                 }
             }
         }
@@ -905,11 +936,11 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
         reinterpret_cast<int32_t *>(out)[e] = pad ? -(1 << 29) : v;
 }
 
-__global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, uint32_t *list,
+__global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, int32_t ceiling, uint32_t *list,
                                              uint32_t *count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && scores[i] >= 32767) list[atomicAdd(count, 1u)] = i;
+    if (i < n && scores[i] >= ceiling) list[atomicAdd(count, 1u)] = i;
 }
 
 // ---------------------------------------------------------------------------
@@ -1215,6 +1246,7 @@ namespace {
 struct DiagVariant {
     SwgKernelInfo info;
     void (*kernel[2])(const SwgDiagParams); // [0] single pass, [1] multi-pass
+    void (*wide)(const SwgDiagParams);      // multi-pass form (also runs one pass), scores to 65535
     void (*dyn)(const SwgDiagDynParams);    // single pass, pairs off a work queue
 };
 template <int K, int MAXW> DiagVariant make_diag()
@@ -1229,6 +1261,7 @@ template <int K, int MAXW> DiagVariant make_diag()
     v.info.lds_fixed = 0;
     v.kernel[0] = swg_diag_kernel<K, MAXW, false>;
     v.kernel[1] = swg_diag_kernel<K, MAXW, true>;
+    v.wide = swg_diag_kernel<K, MAXW, true, true>;
     v.dyn = swg_diag_dyn_kernel<K, MAXW>;
     return v;
 }
@@ -1257,7 +1290,7 @@ SwgKernelInfo swg_diag_variant_info(int variant)
     return diag_variants(&n)[variant].info;
 }
 
-hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, size_t lds_bytes,
+hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int workgroups, size_t lds_bytes,
                            const SwgDiagParams &p, hipStream_t stream)
 {
     int n;
@@ -1265,7 +1298,7 @@ hipError_t swg_launch_diag(int variant, bool multipass, int W, int workgroups, s
     if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
         (p.G != 16 && p.G != 32 && p.G != 64))
         return hipErrorInvalidValue;
-    auto k = v[variant].kernel[multipass ? 1 : 0];
+    auto k = wide ? v[variant].wide : v[variant].kernel[multipass ? 1 : 0];
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -1346,11 +1379,11 @@ hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, 
     return hipGetLastError();
 }
 
-hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, uint32_t *d_list,
+hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling, uint32_t *d_list,
                                         uint32_t *d_count, hipStream_t stream)
 {
     if (n_slots == 0) return hipSuccess;
     hipLaunchKernelGGL(swg_collect_saturated_kernel, dim3((n_slots + 255) / 256), dim3(256), 0,
-                       stream, d_scores, n_slots, d_list, d_count);
+                       stream, d_scores, n_slots, ceiling, d_list, d_count);
     return hipGetLastError();
 }

@@ -16,7 +16,7 @@ def _setup(ctx, g):
 
 
 OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups")
-DEFAULT_ON = ("work_queue", "long_helps")
+DEFAULT_ON = ("work_queue", "long_helps", "wide16")
 
 
 def _reset_options(ctx):
@@ -82,10 +82,17 @@ def test_overflow_is_detected_and_rescored(swg, ctx):
     g = load_golden("pam250_overflow_w")
     _setup(ctx, g)
     db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    # default: the wide form of the diagonal engine (scores to 65535), int32 only beyond that
+    scores, _, st = ctx.search(db)
+    assert np.array_equal(scores, g["oracle32"])
+    assert st["path_bits"] == 16 and st["n_rescored"] == int((g["oracle32"] >= 65535).sum())
+    assert (scores != g["ref16"]).any()      # the reference itself is wrong here (wraps)
+    # plain int16 + int32 re-score of everything that reached 32767
+    ctx.set_option("wide16", 0)
     scores, _, st = ctx.search(db)
     assert np.array_equal(scores, g["oracle32"])
     assert st["path_bits"] == 16 and st["n_rescored"] == int((g["oracle32"] >= 32767).sum())
-    assert (scores != g["ref16"]).any()      # the reference itself is wrong here (wraps)
+    ctx.set_option("wide16", 1)
     db.close()
 
 
@@ -240,14 +247,53 @@ def test_high_similarity_rescore_matches_oracle(swg, ctx, orc):
     want = orc.score_db(q, flat, off, sc.table(), -2, -1)
     assert planted >= 3 and (want > 32767).sum() == planted
     db = swg.Database(flat, off).upload(ctx)
+    # the wide form holds these scores (< 65535): nothing is left for the int32 re-score
     scores, hits, st = ctx.search(db, k=20)
     assert np.array_equal(scores, want)
-    assert st["n_rescored"] == planted and st["passes"] > 1
+    assert st["n_rescored"] == 0 and st["passes"] > 1 and st["engine"] == 2
     assert hits == orc.topk(want, 20)
+    ctx.set_option("wide16", 0)
+    scores0, _, st0 = ctx.search(db)
+    assert np.array_equal(scores0, want) and st0["n_rescored"] == planted
+    ctx.set_option("wide16", 1)
     ctx.set_option("engine", 1)
     scores1, _, st1 = ctx.search(db)
-    assert st1["engine"] == 1 and np.array_equal(scores1, want)
+    assert st1["engine"] == 1 and np.array_equal(scores1, want) and st1["n_rescored"] == planted
     db.close()
+
+
+@pytest.mark.parametrize("geom", [{}, {"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4},
+                                  {"cols_per_wave": 24, "group_lanes": 16, "max_waves": 8, "long_split": 900},
+                                  {"cols_per_wave": 6, "group_lanes": 64, "max_waves": 4},
+                                  {"cols_per_wave": 32, "group_lanes": 32, "max_waves": 4, "long_split": -1}])
+def test_wide16_range_and_beyond(swg, ctx, orc, geom):
+    """Scores in every range at once: below 32767, between 32767 and 65535 (wide form, exact) and
+    above 65535 (flagged by the wide form, re-scored in int32): a tryptophan-rich query (17 per
+    match in PAM250) against copies of its prefixes, short decoys, and a one-pass geometry."""
+    sc = swg.load_scoring("PAM250")
+    rng = np.random.default_rng(33)
+    w = swg.synth_query(1, 1)
+    w[:] = 23  # 'W'
+    q = np.concatenate([np.repeat(w, 4400), swg.synth_query(77, 100)])
+    lens = [4500, 4200, 3000, 2500, 1900, 1000] + [int(v) for v in rng.integers(1, 400, size=500)]
+    seqs = [q[:L].copy() if i < 6 else swg.synth_query(2000 + i, L) for i, L in enumerate(lens)]
+    flat = np.concatenate(seqs)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    assert (want >= 65535).sum() >= 2 and ((want >= 32767) & (want < 65535)).sum() >= 2 and (want < 32767).sum() > 400
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    for k, v in geom.items():
+        ctx.set_option(k, v)
+    db = swg.Database(flat, off).upload(ctx)
+    got, hits, st = ctx.search(db, k=10)
+    assert np.array_equal(got, want), (geom, st)
+    assert st["n_rescored"] == int((want >= 65535).sum()) and st["engine"] == 2
+    assert hits == orc.topk(want, 10)
+    db.close()
+    _reset_options(ctx)
 
 
 @pytest.mark.parametrize("name", ["pam250_lq128", "blosum62_lq367", "blosum62_tiny_db", "blosum62_lq1",
