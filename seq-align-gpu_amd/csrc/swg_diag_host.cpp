@@ -80,7 +80,6 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
             const double cost = instr / (64 / G);                     // per pair-row
             const double depth = ((double)longest_rows + G) * instr * kHotCycles;
             SwgDiagPlan c;
-            memset(&c, 0, sizeof c);
             c.variant = v;
             c.K = info.K;
             c.G = G;
@@ -135,8 +134,17 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                 if (opt_waves > 0 && W != (int)opt_waves) continue;
                 // with the work queue the workgroup size does not matter for balance; four wavefronts
                 // (one per SIMD) interleave the two classes on every CU, larger workgroups partition the
-                // CUs between them (timed faster in isolation, slower back to back)
-                if (dynamic && opt_waves == 0 && wps != 1) continue;
+                // CUs between them (timed faster in isolation, slower back to back).  Larger ones only
+                // where LDS allows a single workgroup per CU and more wavefronts mean more occupancy.
+                if (dynamic && opt_waves == 0 && wps != 1) {
+                    bool improves = true;
+                    for (int w2 = 1; w2 < wps; ++w2) {
+                        const int pc2 = std::max(1, std::min<int>(info.max_waves / (4 * w2), (int)((160 * 1024) / lds)));
+                        if (std::min(4, w2 * pc2) >= std::min(4, wps * std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)))))
+                            improves = false;
+                    }
+                    if (!improves) continue;
+                }
                 const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)));
                 const int eff_wps = std::min(4, wps * per_cu);
                 const double cps = kCyclesPerInstr[eff_wps];
@@ -173,7 +181,6 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                                   instr * cps * eff_wps;
                     uint64_t lstreams = 0;
                     SwgDiagPlan lp;
-                    memset(&lp, 0, sizeof lp);
                     if (split) {
                         // the long pairs have to be done by the time the bulk is
                         const double bulk_cycles = std::max(work / simds, crit);

@@ -48,11 +48,11 @@ struct SwgPairTokens {
 };
 
 struct SwgDiagPlan {
-    int variant, K, G, npass, W, workgroups;
-    int wide; // scores to 65535 (values biased by -32768): fixed streams, multi-pass kernel
-    uint32_t n_streams;
-    size_t lds_bytes;
-    double est_ms;
+    int variant = 0, K = 0, G = 0, npass = 0, W = 0, workgroups = 0;
+    int wide = 0; // scores to 65535 (values biased by -32768): fixed streams, multi-pass kernel
+    uint32_t n_streams = 0;
+    size_t lds_bytes = 0;
+    double est_ms = 0.0;
 };
 // The diagonal engine's work split: class 0 = the bulk of the pairs, class 1 = the few
 // longest ones, which would otherwise be the serial tail of the whole search.  The long

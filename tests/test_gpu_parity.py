@@ -479,6 +479,7 @@ def test_work_queue_variants_agree(swg, ctx, orc):
             got, hits, st = ctx.search(db, k=7)
             assert np.array_equal(got, want), (name, opts, st)
             assert hits == orc.topk(want, 7)
+            assert st["work_queue"] == opts.get("work_queue", 1) and st["passes"] == 1
             # a second search on the same resident database re-arms the queue counters
             got2, _, _ = ctx.search(db, k=0)
             assert np.array_equal(got2, want), (name, opts, "second search")
