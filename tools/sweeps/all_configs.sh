@@ -4,7 +4,7 @@ run() {
 import sys,json
 d=json.loads(sys.stdin.read())
 c=d['config']
-print('$*', '->', d['value'],'GCUPS', c.get('engine'), 'K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'P',c['passes'],'wgs',c['workgroups'],'long',c.get('long_pairs'),'pad', c['cells_padded_over_real'], 'resc', c['n_rescored'], 'step', d['ms_per_step'], 'fill', d['kernel_ms']['fill'], d['roofline']['binding_roof']['frac_of_measured_issue_peak'])
+print('$*', '->', d['value'],'GCUPS', c.get('engine'), 'K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'P',c['passes'],'wgs',c['workgroups'],'long',c.get('long_pairs'),'pad', c['cells_padded_over_real'], 'resc', c['n_rescored'], 'step', d['ms_per_step'], 'fill', d['kernel_ms']['fill'], d['roofline']['binding_roof']['frac_of_issue_peak'])
 "
 }
 timeout -k 10 700 python -m pytest tests -m gpu -x -q 2>&1 | tail -3

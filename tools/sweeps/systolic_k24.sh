@@ -4,7 +4,7 @@ run() {
 import sys,json
 d=json.loads(sys.stdin.read())
 c=d['config']
-print('$*', '->', d['value'],'GCUPS', c.get('engine'), 'K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'P',c['passes'],'wgs',c['workgroups'],'pad', c['cells_padded_over_real'], 'fill', d['kernel_ms']['fill'], d['roofline']['binding_roof']['frac_of_measured_issue_peak'])
+print('$*', '->', d['value'],'GCUPS', c.get('engine'), 'K',c['cols_per_wave'],'G',c.get('group_lanes'),'W',c['waves'],'P',c['passes'],'wgs',c['workgroups'],'pad', c['cells_padded_over_real'], 'fill', d['kernel_ms']['fill'], d['roofline']['binding_roof']['frac_of_issue_peak'])
 "
 }
 A="--config 2 --nseq 570000"
