@@ -694,7 +694,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 // issue port.  With the queue every resident wavefront stays busy until the
 // pairs are gone, whatever rate it ran at.
 //
-// A lane group's bookkeeping lives in LDS (32 dwords per group, after the
+// A lane group's bookkeeping lives in LDS (64 dwords per group, after the
 // profile) and is only touched when one of the wavefront's pairs runs out; between
 // such events a block costs a scalar compare and the leader's token load.  The
 // register file holds the DP state and one token index, which is what lets K=24
@@ -709,12 +709,14 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 //
 // LDS record of a lane group: [0] value of the wavefront's block counter at which
 // the current pair has no more tokens to load (NONE: no pair and none to come),
-// [1] flags, [2] ids pushed, [3] ids popped, [16..31] ring of pair ids.
+// [1] flags, [2] ids pushed, [3] ids popped, [32..63] ring of pair ids.
 #ifndef SWG_DYN_FENCE_ABOVE
 #define SWG_DYN_FENCE_ABOVE 16 // fence the profile prefetch for K above this
 #endif
-#define SWG_DYN_STATE 32u
-#define SWG_DYN_RING 16u
+#define SWG_DYN_STATE 64u
+// Pairs between the leader (which is up to two token blocks ahead) and the tail lane: at most
+// (2*4 + 63) rows / 4 rows per shortest pair = 18 with 64 lanes per pair.
+#define SWG_DYN_RING 32u
 #ifndef SWG_DYN_TURN_SHIFT
 #define SWG_DYN_TURN_SHIFT 14 // a turn lasts 2^14 ticks of the 100 MHz clock (164 us): long against a block even for the wavefront whose turn it is to yield
 #endif
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     const uint32_t len = p.pair_off[nq + 1u] - bi;
                     end_at = blocks + len;
                     const uint32_t pushed = st[2];
-                    st[16u + (pushed & (SWG_DYN_RING - 1u))] = nq;
+                    st[SWG_DYN_RING + (pushed & (SWG_DYN_RING - 1u))] = nq;
                     st[2] = pushed + 1u;
                     if (len >= (second ? p.prio_blocks2 : p.prio_blocks)) fl |= SWG_DYN_HOT;
                 } else {
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             if (special && tail && (tok & SWG_TOK_LAST)) {
                 uint32_t *st = record();
                 const uint32_t popped = st[3];
-                const uint32_t pr = st[16u + (popped & (SWG_DYN_RING - 1u))];
+                const uint32_t pr = st[SWG_DYN_RING + (popped & (SWG_DYN_RING - 1u))];
                 st[3] = popped + 1u;
                 p.scores[2u * pr] = (int)(c_out & 0xFFFFu);
                 p.scores[2u * pr + 1u] = (int)(c_out >> 16);

@@ -459,6 +459,7 @@ def test_work_queue_variants_agree(swg, ctx, orc):
     shapes = {
         "tiny": [1, 2, 3],                                           # 2 pairs: most queue shards empty
         "short": [int(v) for v in rng.integers(1, 12, size=3000)],   # pairs far shorter than 16..64 rows
+        "tiniest": [1, 2] * 30000,     # every pair is one token block: up to 18 pairs inside a 64-lane group
         "mixed": [4000, 2500, 1, 1, 2] + [int(v) for v in rng.integers(5, 700, size=6000)],
     }
     for name, lens in shapes.items():
