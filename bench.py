@@ -19,7 +19,13 @@ import os
 import sys
 import time
 
-import numpy as np
+# The HIP runtime multiplexes a process's streams onto 4 hardware queues by default; the library's
+# two fill streams plus torch's current, copy and RCCL streams are more than that, and streams
+# that share a queue serialise (measured: the top-K all-reduce waits behind a whole fill and the
+# step grows by 0.4 ms).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -133,9 +139,14 @@ def main():
     K = args.topk
     merger = TopKMerger(swg, K, rank, world, "cuda") if use_dist else None
 
-    # Steps are software-pipelined two deep: search i+1 is queued on the GPU before the host
-    # finishes search i (top-K read-out, and for N > 1 the all-reduce merge), so host-side work
-    # overlaps the next fill.  Every step still does all of its work inside the timed region.
+    # Steps are software-pipelined: search i+1 (and, for N > 1, i+2) is queued on the GPU before the
+    # host finishes search i (top-K read-out, and for N > 1 the all-reduce merge), so host-side work
+    # overlaps the next fill.  The fill kernels are persistent and hold every wave slot, so the
+    # all-reduce kernel of step i only gets onto the GPU when fill i+1 drains: with one more search
+    # already queued behind it the GPU does not wait for the host in that gap.  Every step still
+    # does all of its work inside the timed region.
+    depth = 1 if args.no_pipeline else (3 if use_dist else 2)
+
     def finish(ticket):
         if use_dist:
             keys, st = ctx.search_end_keys(ticket)
@@ -144,17 +155,13 @@ def main():
         return hits, st
 
     def run_steps(n, record):
-        pending = None
+        pending = []
         for _ in range(n):
-            t = ctx.search_begin(db, K)
-            if args.no_pipeline:
-                record(*finish(t))
-                continue
-            if pending is not None:
-                record(*finish(pending))
-            pending = t
-        if pending is not None:
-            record(*finish(pending))
+            pending.append(ctx.search_begin(db, K))
+            if len(pending) >= depth:
+                record(*finish(pending.pop(0)))
+        while pending:
+            record(*finish(pending.pop(0)))
 
     run_steps(args.warmup, lambda hits, st: None)
 

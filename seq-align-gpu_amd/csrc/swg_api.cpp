@@ -488,14 +488,14 @@ static bool diag_class_is_dynamic(const swg_ctx *ctx, const swg_db *db, const Sw
 static int diag_class_workgroups(const swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int c)
 {
     const SwgDiagPlan &pl = wk.plan[c];
-    if (c != 0 || wk.n_classes != 2 || !diag_class_is_dynamic(ctx, db, pl) ||
-        !diag_class_is_dynamic(ctx, db, wk.plan[1]))
-        return pl.workgroups;
+    if (c != 0 || !diag_class_is_dynamic(ctx, db, pl)) return pl.workgroups;
     const SwgKernelInfo info = swg_diag_variant_info(pl.variant);
     const size_t lds = swg_diag_dyn_lds_bytes(pl.K, pl.G, pl.W);
     const int per_cu = std::max(1, std::min<int>(info.max_waves / pl.W, (int)((160 * 1024) / lds)));
     const int capacity = ctx->n_cu * per_cu;
-    const int displaced = (wk.plan[1].workgroups * wk.plan[1].W + pl.W - 1) / pl.W;
+    int displaced = 0;
+    if (wk.n_classes == 2 && diag_class_is_dynamic(ctx, db, wk.plan[1]))
+        displaced = (wk.plan[1].workgroups * wk.plan[1].W + pl.W - 1) / pl.W;
     return std::max(1, std::min(pl.workgroups, capacity - displaced));
 }
 
