@@ -261,6 +261,8 @@ void swg_db_release_device(swg_db *db)
     }
     (void)hipFree(db->ptok.d_tok);
     (void)hipFree(db->ptok.d_pair_off);
+    (void)hipFree(db->ptok.d_edge[0]);
+    (void)hipFree(db->ptok.d_edge[1]);
     db->ptok = SwgPairTokens();
     for (SwgDiagLayout &L : db->diag) {
         (void)hipFree(L.d_tok);
@@ -475,11 +477,13 @@ static int ensure_pair_tokens(swg_ctx *ctx, swg_db *db)
     return SWG_OK;
 }
 
-// Single-pass classes take their pairs off a work queue; multi-pass ones keep static streams
-// (a pair's edge spill has to be read back by the lane group that wrote it).
+// Classes take their pairs off a work queue (several passes: one launch per pass, the rows' edges
+// go from launch to launch through memory); fixed streams only on request or when the database is
+// too large for the queue's 32-bit row indices.
 static bool diag_class_is_dynamic(const swg_ctx *ctx, const swg_db *db, const SwgDiagPlan &pl)
 {
-    return pl.npass == 1 && !pl.wide && ctx->opt_dynamic != 0 && db->ptok.ok;
+    if (ctx->opt_dynamic == 0 || !db->ptok.ok) return false;
+    return pl.npass == 1 || db->ptok.total_blocks < (1ull << 30);
 }
 
 // Workgroups to launch for class c.  Work-queue kernels are persistent: a workgroup that is not
@@ -539,6 +543,10 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
         if (!diag_class_is_dynamic(ctx, db, wk.plan[c])) {
             int rc = ensure_diag_layout(ctx, db, c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
             if (rc != SWG_OK) return rc;
+        } else if (wk.plan[c].npass > 1 && !db->ptok.d_edge[0]) {
+            const size_t bytes = std::max<size_t>(8, (size_t)db->ptok.total_blocks * 4 * sizeof(uint2));
+            HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[0], bytes));
+            HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[1], bytes));
         }
         const int slot = diag_profile_slot(wk.plan[c]);
         ncols[slot] = std::max<uint32_t>(ncols[slot], (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
@@ -611,8 +619,18 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
             q.simd_ranks = db->d_counters + SWG_RANK_WORD(c);
             q.trace = d_trace[c];
-            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, pl.W, diag_class_workgroups(ctx, db, wk, c), q,
-                                             c == 1 ? ctx->stream2 : s));
+            const bool edges = pl.npass > 1 || pl.wide != 0;
+            const size_t slice = (size_t)pl.G * pl.K * 64;
+            hipStream_t qs = c == 1 ? ctx->stream2 : s;
+            for (int pass = 0; pass < pl.npass; ++pass) {
+                // one launch per pass: the kernel boundary is what lets any lane group take any pair
+                if (pass > 0)
+                    HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, qs));
+                q.profile = ctx->d_profile[diag_profile_slot(pl)] + (size_t)pass * slice;
+                q.edge_in = pass > 0 ? T.d_edge[(pass - 1) & 1] : nullptr;
+                q.edge_out = pass + 1 < pl.npass ? T.d_edge[pass & 1] : nullptr;
+                HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pl.wide != 0, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
+            }
             continue;
         }
         SwgDiagParams d;
@@ -934,16 +952,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // int16: the diagonal engine unless the systolic one is asked for
     SwgDiagWork wk;
     bool use_diag = false, tuned_systolic = false;
-    if (wide) {
-        // wide form: fixed streams (its kernel is the multi-pass one), model-chosen geometry
-        use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
-                                      ctx->opt_long_split, ctx->opt_workgroups == 0, false, &wk) > 0;
-        if (use_diag)
-            for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].wide = 1;
-        else
-            wide = false; // no geometry: the plain form and the int32 re-score
-    }
-    if (bits == 16 && ctx->opt_engine != 1 && !wide) {
+    if (bits == 16 && ctx->opt_engine != 1) {
         if (ctx->opt_dynamic && (rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
         const bool free_geometry = ctx->opt_cols == 0 && ctx->opt_group == 0 && ctx->opt_max_waves == 0 &&
                                    ctx->opt_long_split == 0 && ctx->opt_workgroups == 0;
@@ -955,7 +964,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             if (autotune_diag(ctx, mdb, lq, go, ge, &tn) == SWG_OK && tn.wk.n_classes > 0)
                 it = mdb->tuned.insert(std::make_pair((uint64_t)lq, tn)).first;
         }
-        if (it != mdb->tuned.end()) {
+        if (it != mdb->tuned.end() && !(wide && it->second.engine == 1)) {
             if (it->second.engine == 1 && ctx->opt_engine == 0) {
                 // the systolic engine measured faster for this database and query length
                 const long keep = ctx->opt_cols;
@@ -982,6 +991,11 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             d0.n_streams = (uint32_t)((uint64_t)d0.workgroups * per_wg);
         }
         if (!use_diag && !tuned_systolic && rc != SWG_OK) return rc;
+        // the wide form exists in the diagonal engine only
+        if (wide && use_diag)
+            for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].wide = 1;
+        else
+            wide = false;
     }
     const SwgDiagPlan &dpl = wk.plan[0];
     const bool may_saturate = bits == 16 && score_bound >= (wide ? 65535ull : 32767ull);

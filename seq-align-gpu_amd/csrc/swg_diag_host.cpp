@@ -49,6 +49,9 @@ uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)
 //   (64 lanes per pair, fewest columns per lane, raised wave priority) so that (b) does not
 //   dominate small databases.
 static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 18.0 : 14.0); }
+// one pass of several through the work queue: row index, edge hand-over to the leader, parking the
+// tail's edge
+static const double kEdgeInstr = 7.0;
 
 // Long class: the cheapest geometry (instructions per pair-row, column padding included)
 // whose longest chain still finishes within `budget_cycles`; if none does, the shortest chain.
@@ -124,10 +127,11 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
             if (lds > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
             const int NG = 64 / G;
-            const double instr = instr_per_row(info.K, G);
-            // single-pass classes take pairs off a queue: no fixed shares, the chain that matters is
-            // the longest pair at the rate of a wavefront that gets its fair share of the SIMD
-            const bool dynamic = work_queue && npass == 1;
+            // with the work queue (several passes: one launch per pass) there are no fixed shares, the
+            // chain that matters is the longest pair at the rate of a wavefront that gets its fair
+            // share of the SIMD
+            const bool dynamic = work_queue && (npass == 1 || db->n_local < (1u << 30));
+            const double instr = instr_per_row(info.K, G) + (dynamic && npass > 1 ? kEdgeInstr : 0.0);
             for (int wps = 1; wps <= 4; ++wps) {
                 const int W = 4 * wps;
                 if (W > info.max_waves) continue;
@@ -150,7 +154,8 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                 const double cps = kCyclesPerInstr[eff_wps];
                 const uint64_t spw = (uint64_t)W * NG;
                 const uint64_t hw_streams = (uint64_t)n_cu * per_cu * spw;
-                for (int split = 0; split <= (have_long ? 3 : 0); ++split) {
+                // (a long class beside a multi-pass queue launch would need its own edge buffers: not built)
+                for (int split = 0; split <= (have_long && !(dynamic && npass > 1) ? 3 : 0); ++split) {
                     uint64_t n_long = 0, rows_long = 0, longest_bulk = longest, longest_long = 0;
                     uint64_t streams0 = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, n_pairs));
                     streams0 = (streams0 + spw - 1) / spw * spw;
@@ -207,7 +212,10 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                         crit = std::max(crit, lcrit);
                     }
                     double cycles = std::max(work / simds, crit);
-                    cycles *= 1.0 + 0.04 * (npass - 1); // profile reloads, pass barriers, edge spills
+                    if (dynamic)
+                        cycles += (npass - 1) * 0.15e-3 * 2.35e9; // a launch per pass: drain and ramp
+                    else
+                        cycles *= 1.0 + 0.04 * (npass - 1); // profile reloads, pass barriers, edge spills
                     // fixed streams lose what the work queue was built to recover (uneven wavefront
                     // rates, a thinning tail): measured 4 900 against 5 600 GCUPS on config 2
                     if (!dynamic) cycles *= 1.15;

@@ -44,12 +44,13 @@ struct SwgPairTokens {
     uint64_t total_blocks = 0;
     uint2 *d_tok = nullptr;
     uint32_t *d_pair_off = nullptr;
+    uint2 *d_edge[2] = {nullptr, nullptr};    // multi-pass: (M,B) per row between consecutive passes, ping-pong
     std::vector<uint32_t> pair_blocks_prefix; // host copy of pair_off
 };
 
 struct SwgDiagPlan {
     int variant = 0, K = 0, G = 0, npass = 0, W = 0, workgroups = 0;
-    int wide = 0; // scores to 65535 (values biased by -32768): fixed streams, multi-pass kernel
+    int wide = 0; // scores to 65535 (values biased by -32768)
     uint32_t n_streams = 0;
     size_t lds_bytes = 0;
     double est_ms = 0.0;

@@ -68,7 +68,9 @@ struct SwgDiagDynParams {
     uint32_t go, ge;          // |gap_open+gap_extend|, |gap_extend| in both halves
     uint32_t prio_blocks;     // a wavefront feeding a pair of >= this many blocks runs at raised priority
     uint32_t prio_blocks2;    // the same for pairs of the second range
-    uint32_t *simd_ranks;     // [SWG_DYN_SIMD_SLOTS] zero before the launch
+    uint32_t *simd_ranks;     // [SWG_DYN_SIMD_SLOTS] zero before the search
+    const uint2 *edge_in;     // one pass of several: (M,B) left edge per row from the previous pass (null: first)
+    uint2 *edge_out;          // ... right edge per row for the next pass (null: last)
     uint32_t turn_levels;     // priorities the other wavefronts rotate through: 3 beside a long class, else 4
     uint64_t *trace;          // diagnostics (SWG_TRACE) or null
 };
@@ -100,7 +102,8 @@ SwgKernelInfo swg_diag_variant_info(int variant); // K, max_waves (wave budget o
 hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int workgroups, size_t lds_bytes,
                            const SwgDiagParams &p, hipStream_t stream);
 size_t swg_diag_dyn_lds_bytes(int K, int G, int W);
-hipError_t swg_launch_diag_dyn(int variant, int W, int workgroups, const SwgDiagDynParams &p, hipStream_t stream);
+hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int workgroups, const SwgDiagDynParams &p,
+                               hipStream_t stream);
 
 // profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
 // col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.

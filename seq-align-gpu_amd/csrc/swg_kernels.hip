@@ -728,9 +728,32 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 #define SWG_DYN_NONE 0xFFFFFFFFu
 // flags bits 8..: shards of the current range found empty so far
 
-template <int K, int MAXW>
+// quad_perm DPP controls: every lane of a quad reads the quad's lane Q
+#define DPP_QUAD(Q) ((Q) | ((Q) << 2) | ((Q) << 4) | ((Q) << 6))
+// value of lane r of the caller's quad (r is a constant after unrolling)
+DEVINL uint32_t quad_bcast(uint32_t x, int r)
+{
+    switch (r) {
+    case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, DPP_QUAD(0), 0xf, 0xf, true);
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, DPP_QUAD(1), 0xf, 0xf, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, DPP_QUAD(2), 0xf, 0xf, true);
+    default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, DPP_QUAD(3), 0xf, 0xf, true);
+    }
+}
+
+// EDGES: the launch is one pass of a query longer than G*K columns.  The left edge of every row
+// comes from the previous pass's launch (edge_in, null in the first pass) and the right edge goes
+// to the next one (edge_out, null in the last), both indexed by the row's position in the pair-major
+// token order, so any lane group can take any pair in any pass; the kernel boundary is the
+// synchronisation.  Scores are the maximum over the passes.  Costs seven instructions per row: the
+// row index travels with the token; the first four lanes of a group each prefetch one row's edge of
+// the next block and hand it to the leader with a quad broadcast; the tail lane stores its edge
+// every row.
+// WIDE: scores to 65535 (see CellsDiag); needs EDGES (a query that can pass 32767 is long).
+template <int K, int MAXW, bool EDGES = false, bool WIDE = false>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDynParams p)
 {
+    static_assert(EDGES || !WIDE, "the wide form is instantiated with edges only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile, then the group records
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -740,6 +763,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     const int g = lane & (G - 1);
     const bool leader = g == 0, tail = g == G - 1;
     constexpr int CH = CellsDiag<K>::CH;
+    constexpr uint32_t Z = CellsDiag<K, WIDE>::ZERO; // score 0 in the cells' representation
     const uint32_t base = (uint32_t)g * (K / CH) * CellsDiag<K>::CHUNK;
     const uint32_t slice = (uint32_t)G * K * 64u;
     // recomputed where it is needed (rarely) instead of living in a register
@@ -753,11 +777,15 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     if (g < 4) record()[g] = 0u; // every group is due at block 0
     __syncthreads();
 
-    CellsDiag<K> cells;
+    CellsDiag<K, WIDE> cells;
     cells.reset();
-    uint32_t tok = 0u, m_out = 0u, b_out = 0u, c_out = 0u;
+    uint32_t tok = 0u, m_out = Z, b_out = Z, c_out = Z;
     uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
     uint32_t bi = SWG_DYN_NONE;  // leader lane: next token block of the pair it feeds (none: idle)
+    // EDGES: block index of cur / nxt (leader), row index travelling with the token, left edges of
+    // the current / next block (lanes 0..3 of a group, one row each)
+    uint32_t bcur = SWG_DYN_NONE, bnxt = SWG_DYN_NONE, ridx = SWG_DYN_NONE;
+    uint2 ec = make_uint2(Z, Z), en = make_uint2(Z, Z);
     // wave-uniform: block counter, the count at which the next pair runs out (none: all leaders idle)
     uint32_t blocks = 0u, next_event = 0u, drain = 0u, events = 0u;
     uint64_t event_ticks = 0ull; // diagnostics
@@ -853,35 +881,56 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         }
         cur = nxt;
         nxt = make_uint2(0u, 0u);
+        if (EDGES) {
+            bcur = bnxt;
+            bnxt = bi;
+            ec = en;
+        }
         if (bi != SWG_DYN_NONE) {
             nxt = p.tok[bi];
             ++bi;
+        }
+        if (EDGES) {
+            // lanes 0..3 of a group fetch the next block's left edges, one row each
+            const uint32_t bq = quad_bcast(bnxt, 0);
+            en = make_uint2(Z, Z);
+            if (g < 4 && bq != SWG_DYN_NONE && p.edge_in) en = p.edge_in[(size_t)bq * 4u + (uint32_t)g];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t word = (r & 2) ? cur.y : cur.x;
             const uint32_t fresh = (r & 1) ? (word >> 16) : (word & 0xFFFFu);
+            uint32_t lm = Z, lb = Z, fresh_ridx = SWG_DYN_NONE;
+            if (EDGES) {
+                lm = quad_bcast(ec.x, r);
+                lb = quad_bcast(ec.y, r);
+                fresh_ridx = bcur != SWG_DYN_NONE ? bcur * 4u + (uint32_t)r : SWG_DYN_NONE;
+            }
             uint32_t em, eb, cin;
             if (G == 16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
-                em = dpp_zero<DPP_ROW_SHR1>(m_out);
-                eb = dpp_zero<DPP_ROW_SHR1>(b_out);
-                cin = dpp_zero<DPP_ROW_SHR1>(c_out);
+                em = EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, m_out) : dpp_zero<DPP_ROW_SHR1>(m_out);
+                eb = EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, b_out) : dpp_zero<DPP_ROW_SHR1>(b_out);
+                cin = WIDE ? dpp_keep<DPP_ROW_SHR1>(Z, c_out) : dpp_zero<DPP_ROW_SHR1>(c_out);
+                if (EDGES) ridx = dpp_keep<DPP_ROW_SHR1>(fresh_ridx, ridx);
             } else {
                 const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
-                const uint32_t u1 = dpp_zero<DPP_WAVE_SHR1>(m_out);
-                const uint32_t u2 = dpp_zero<DPP_WAVE_SHR1>(b_out);
-                const uint32_t u3 = dpp_zero<DPP_WAVE_SHR1>(c_out);
+                const uint32_t u1 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lm, m_out) : dpp_zero<DPP_WAVE_SHR1>(m_out);
+                const uint32_t u2 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lb, b_out) : dpp_zero<DPP_WAVE_SHR1>(b_out);
+                const uint32_t u3 = WIDE ? dpp_keep<DPP_WAVE_SHR1>(Z, c_out) : dpp_zero<DPP_WAVE_SHR1>(c_out);
+                const uint32_t u4 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(fresh_ridx, ridx) : 0u;
                 if (G == 32) { // lane 32 starts a group too
                     tok = leader ? fresh : u0;
-                    em = leader ? 0u : u1;
-                    eb = leader ? 0u : u2;
-                    cin = leader ? 0u : u3;
+                    em = leader ? lm : u1;
+                    eb = leader ? lb : u2;
+                    cin = leader ? Z : u3;
+                    if (EDGES) ridx = leader ? fresh_ridx : u4;
                 } else {
                     tok = u0;
                     em = u1;
                     eb = u2;
                     cin = u3;
+                    if (EDGES) ridx = u4;
                 }
             }
             const uint32_t ox = CH == 4 ? (tok & 0xF8u) : ((tok >> 1) & 0x7Cu);
@@ -890,9 +939,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             uint32_t go_t = p.go, ge_t = p.ge;
             if (special) {
                 const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
-                cells.best &= ~fm;
-                go_t |= fm;
-                ge_t |= fm;
+                if (WIDE) {
+                    cells.wipe(fm);
+                } else {
+                    cells.best &= ~fm;
+                    go_t |= fm;
+                    ge_t |= fm;
+                }
             }
             const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(smem, base + ox, base + oy, em, eb, go_t, ge_t);
             c_out = pk_max_i16(cin, cells.best);
@@ -901,11 +954,20 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 const uint32_t popped = st[3];
                 const uint32_t pr = st[SWG_DYN_RING + (popped & (SWG_DYN_RING - 1u))];
                 st[3] = popped + 1u;
-                p.scores[2u * pr] = (int)(c_out & 0xFFFFu);
-                p.scores[2u * pr + 1u] = (int)(c_out >> 16);
+                if (EDGES) { // one pass of several: the score is the maximum over the passes
+                    atomicMax(p.scores + 2u * pr, (int)((c_out ^ Z) & 0xFFFFu));
+                    atomicMax(p.scores + 2u * pr + 1u, (int)((c_out ^ Z) >> 16));
+                } else {
+                    p.scores[2u * pr] = (int)(c_out & 0xFFFFu);
+                    p.scores[2u * pr + 1u] = (int)(c_out >> 16);
+                }
             }
             m_out = e.x;
             b_out = e.y;
+            if (EDGES) {
+                // the tail lane's row is the pass's right edge (L2 gathers a pair's consecutive rows)
+                if (tail && ridx != SWG_DYN_NONE && p.edge_out) p.edge_out[ridx] = e;
+            }
         }
         ++blocks;
         if (!hot && (blocks & (SWG_DYN_TURN_EVERY - 1u)) == 0u) take_turn();
@@ -1249,7 +1311,7 @@ struct DiagVariant {
     SwgKernelInfo info;
     void (*kernel[2])(const SwgDiagParams); // [0] single pass, [1] multi-pass
     void (*wide)(const SwgDiagParams);      // multi-pass form (also runs one pass), scores to 65535
-    void (*dyn)(const SwgDiagDynParams);    // single pass, pairs off a work queue
+    void (*dyn[3])(const SwgDiagDynParams); // pairs off a work queue: single pass; one pass of several; the same, wide form
 };
 template <int K, int MAXW> DiagVariant make_diag()
 {
@@ -1264,7 +1326,9 @@ template <int K, int MAXW> DiagVariant make_diag()
     v.kernel[0] = swg_diag_kernel<K, MAXW, false>;
     v.kernel[1] = swg_diag_kernel<K, MAXW, true>;
     v.wide = swg_diag_kernel<K, MAXW, true, true>;
-    v.dyn = swg_diag_dyn_kernel<K, MAXW>;
+    v.dyn[0] = swg_diag_dyn_kernel<K, MAXW, false, false>;
+    v.dyn[1] = swg_diag_dyn_kernel<K, MAXW, true, false>;
+    v.dyn[2] = swg_diag_dyn_kernel<K, MAXW, true, true>;
     return v;
 }
 const DiagVariant *diag_variants(int *n)
@@ -1313,7 +1377,8 @@ size_t swg_diag_dyn_lds_bytes(int K, int G, int W)
     return (size_t)G * K * 64u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
 }
 
-hipError_t swg_launch_diag_dyn(int variant, int W, int workgroups, const SwgDiagDynParams &p, hipStream_t stream)
+hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int workgroups, const SwgDiagDynParams &p,
+                               hipStream_t stream)
 {
     int n;
     const DiagVariant *v = diag_variants(&n);
@@ -1321,7 +1386,7 @@ hipError_t swg_launch_diag_dyn(int variant, int W, int workgroups, const SwgDiag
         (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
         return hipErrorInvalidValue;
     const size_t lds = swg_diag_dyn_lds_bytes(v[variant].info.K, (int)p.G, W);
-    auto k = v[variant].dyn;
+    auto k = v[variant].dyn[wide ? 2 : edges ? 1 : 0];
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -488,6 +488,54 @@ def test_work_queue_variants_agree(swg, ctx, orc):
     _reset_options(ctx)
 
 
+def test_multipass_through_the_work_queue(swg, ctx, orc):
+    """A query of several passes: one work-queue launch per pass, edges handed from launch to
+    launch.  Same scores as fixed streams and as the systolic engine, for every lane-group width,
+    also when pairs are much shorter than a lane group (edges of idle and reset rows)."""
+    g = load_golden("blosum62_lq3000")
+    _setup(ctx, g)
+    db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    for opts in ({}, {"cols_per_wave": 16, "group_lanes": 16, "max_waves": 4},
+                 {"cols_per_wave": 12, "group_lanes": 32, "max_waves": 8},
+                 {"cols_per_wave": 8, "group_lanes": 64, "max_waves": 4},
+                 {"cols_per_wave": 32, "group_lanes": 16, "max_waves": 4},
+                 {"cols_per_wave": 6, "group_lanes": 16, "max_waves": 4}):
+        _reset_options(ctx)
+        ctx.set_option("engine", 2)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        scores, _, st = ctx.search(db)
+        assert np.array_equal(scores, g["oracle32"]), (opts, st)
+        assert st["work_queue"] == 1 and st["passes"] > 1
+        ctx.set_option("work_queue", 0)
+        scores0, _, st0 = ctx.search(db)
+        assert np.array_equal(scores0, g["oracle32"]) and st0["work_queue"] == 0 and st0["passes"] == st["passes"]
+    db.close()
+    # short and tiny sequences against a long query
+    sc = swg.load_scoring("BLOSUM62")
+    rng = np.random.default_rng(5)
+    q = swg.synth_query(91, 1500)
+    lens = [3000, 1, 2, 3] + [int(v) for v in rng.integers(1, 60, size=4000)]
+    seqs = [swg.synth_query(500 + i, L) for i, L in enumerate(lens)]
+    flat = np.concatenate(seqs)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    for opts in ({"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4}, {"cols_per_wave": 6, "group_lanes": 64, "max_waves": 4}):
+        _reset_options(ctx)
+        ctx.set_option("engine", 2)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        db = swg.Database(flat, off).upload(ctx)
+        got, _, st = ctx.search(db)
+        assert np.array_equal(got, want), (opts, st)
+        assert st["work_queue"] == 1 and st["passes"] > 1
+        db.close()
+    _reset_options(ctx)
+
+
 def test_group_with_rccl_merge(swg, orc):
     """swg_group on this box's one GPU with the collective forced: shard packing, concurrent
     begin/end, the RCCL max-all-reduce of the hit keys and the final merge all run; results are
