@@ -757,7 +757,8 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
                    (c.n_classes < 2 || (p.plan[1].K == c.plan[1].K && p.plan[1].G == c.plan[1].G &&
                                         p.pair_end[1] == c.pair_end[1]));
         if (!dup) pick.push_back(c);
-        if (pick.size() >= 8) break;
+        // long fills: fewer trials (a trial is a warm-up and a few complete fills)
+        if (pick.size() >= (cands[0].plan[0].est_ms > 50.0 ? 4u : 8u)) break;
     }
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     double best_ms = 1e300;
@@ -767,7 +768,7 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
     auto time_one = [&](const SwgDiagWork &c, double *ms_out) -> int {
         int rc = prepare_diag(ctx, db, c);
         if (rc != SWG_OK) return rc;
-        const int reps = 4;
+        const int reps = c.plan[0].est_ms > 20.0 ? 2 : 4;
         for (int rep = -1; rep < reps; ++rep) {
             bool two = false;
             if (rep == 0) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[0], ctx->stream));
@@ -830,10 +831,11 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
     }
     tuned->engine = 2;
     tuned->ms = best_ms;
-    // third stage: the systolic engine has less bookkeeping per row and wins on large databases,
-    // where its coarse work units (128 sequences x all waves of a workgroup) no longer matter
+    // third stage: the systolic engine (less bookkeeping per row, coarse work units); it has not won
+    // a measured case since the diagonal engine got its work queue and is only tried where a trial
+    // is cheap
     const long keep_cols = ctx->opt_cols;
-    for (int v = 0; v < swg_num_variants(16); ++v) {
+    for (int v = 0; v < swg_num_variants(16) && tuned->ms < 100.0; ++v) {
         Plan pl;
         memset(&pl, 0, sizeof pl);
         ctx->opt_cols = swg_variant_info(16, v).K;
