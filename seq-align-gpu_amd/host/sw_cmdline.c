@@ -42,7 +42,10 @@ static void usage(const char *argv0, const char *err)
             "    --printmatrices --pretty --colour --scoring <x>   accepted, no effect\n"
             "    --topk <K>           append the K best hits (score, index, name)\n"
             "    --gpu <N>            HIP device ordinal [default: 0]\n"
-            "    --gpus <N>           shard the database over GPUs 0..N-1 (RCCL top-K merge)\n",
+            "    --gpus <N>           shard the database over GPUs 0..N-1 (RCCL top-K merge)\n"
+            "    --savedb <file>      also write the packed database (sorted, binned, dword-packed)\n"
+            "    --packed             the database file is such a packed database: no parsing,\n"
+            "                         no sorting; record names and sequences are not in it\n",
             argv0);
     exit(EXIT_FAILURE);
 }
@@ -67,8 +70,8 @@ int main(int argc, char **argv)
 {
     swg_scoring sc;
     swg_scoring_init(&sc);
-    const char *qpath = NULL, *dbpath = NULL;
-    int print_seq = 0, print_fasta = 0, have_matrix = 0;
+    const char *qpath = NULL, *dbpath = NULL, *savedb = NULL;
+    int print_seq = 0, print_fasta = 0, have_matrix = 0, packed = 0;
     long topk = 0, gpu = 0, gpus = 0, v;
     if (argc == 1) usage(argv[0], NULL);
     for (int i = 1; i < argc; i++)
@@ -105,6 +108,11 @@ int main(int argc, char **argv)
         } else if (!strcasecmp(a, "--topk")) {
             if (!parse_int(argv[i + 1], 0, 1 << 20, &topk)) usage(argv[0], "Invalid --topk argument");
             i++;
+        } else if (!strcasecmp(a, "--savedb")) {
+            if (i >= argc - 1) usage(argv[0], "--savedb takes a file name");
+            savedb = argv[++i];
+        } else if (!strcasecmp(a, "--packed")) {
+            packed = 1;
         } else if (!strcasecmp(a, "--gpus")) {
             if (!parse_int(argv[i + 1], 1, 64, &gpus)) usage(argv[0], "Invalid --gpus argument");
             i++;
@@ -126,6 +134,8 @@ int main(int argc, char **argv)
     }
     if (!qpath || !dbpath) usage(argv[0], "Both query and database files must be provided");
     if (!have_matrix) usage(argv[0], "--substitution_matrix is required (the fill scores from the matrix only)");
+    if (packed && (print_seq || print_fasta)) usage(argv[0], "--printseq/--printfasta need the FASTA database, not --packed");
+    if ((packed || savedb) && gpus > 0) usage(argv[0], "--packed/--savedb work with one GPU (--gpu)");
 
     char err[512];
     swg_seqs q, db;
@@ -137,13 +147,21 @@ int main(int argc, char **argv)
         fprintf(stderr, "Error: Query file %s is empty or invalid\n", qpath);
         return EXIT_SUCCESS;
     }
-    if (swg_seqs_read(dbpath, 0, &db, err, sizeof err) != SWG_OK) {
+    swg_db *pdb = NULL;
+    memset(&db, 0, sizeof db);
+    if (packed) {
+        if (swg_db_load(dbpath, &pdb) != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", swg_global_error());
+            return EXIT_SUCCESS;
+        }
+        db.n = swg_db_total_count(pdb);
+    } else if (swg_seqs_read(dbpath, 0, &db, err, sizeof err) != SWG_OK) {
         fprintf(stderr, "Error: couldn't open database file %s\n", dbpath);
         return EXIT_SUCCESS;
     }
     const size_t lq = (size_t)q.seq_off[1];
     int8_t *qidx = (int8_t *)malloc(lq);
-    int8_t *didx = (int8_t *)malloc(db.n ? (size_t)db.seq_off[db.n] + 1 : 1);
+    int8_t *didx = (int8_t *)malloc(db.n && !packed ? (size_t)db.seq_off[db.n] + 1 : 1);
     if (!qidx || !didx) {
         fprintf(stderr, "Error: out of memory\n");
         return EXIT_FAILURE;
@@ -155,14 +173,13 @@ int main(int argc, char **argv)
         if (swg_seqs_to_indices(&q1, qidx, &bad) != SWG_OK) die_illegal(bad);
     }
     swg_query_sanitize(&sc, qidx, lq); /* reference src/alignment_cmdline.c:391-396 */
-    if (swg_seqs_to_indices(&db, didx, &bad) != SWG_OK) die_illegal(bad);
+    if (!packed && swg_seqs_to_indices(&db, didx, &bad) != SWG_OK) die_illegal(bad);
 
     int32_t *scores = (int32_t *)calloc(db.n ? db.n : 1, sizeof(int32_t));
     swg_hit *hits = (swg_hit *)calloc(topk ? (size_t)topk : 1, sizeof(swg_hit));
     size_t n_hits = 0;
     double total_ms = 0.0;
     swg_ctx *ctx = NULL;
-    swg_db *pdb = NULL;
     swg_group *grp = NULL;
     if (gpus > 0) {
         /* database sharded over several GPUs of this process */
@@ -195,9 +212,16 @@ int main(int argc, char **argv)
         memset(&st, 0, sizeof st);
         int rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
         if (rc == SWG_OK) rc = swg_set_query(ctx, qidx, lq);
-        if (rc == SWG_OK) {
+        if (rc == SWG_OK && !packed) {
             rc = swg_db_pack(didx, db.seq_off, db.n, 0, 1, &pdb);
             if (rc != SWG_OK) fprintf(stderr, "Error: %s\n", swg_global_error());
+        }
+        if (rc == SWG_OK && savedb) {
+            if (swg_db_save(pdb, savedb) != SWG_OK) {
+                fprintf(stderr, "Error: %s\n", swg_global_error());
+                return EXIT_FAILURE;
+            }
+            fprintf(stderr, "packed database written to %s\n", savedb);
         }
         if (rc == SWG_OK) rc = swg_db_upload(ctx, pdb);
         if (rc == SWG_OK) rc = swg_search(ctx, pdb, scores, hits, (size_t)topk, &n_hits, &st);
@@ -238,7 +262,7 @@ int main(int argc, char **argv)
     if (topk > 0) {
         printf("Top %lu hits (score, entry, name):\n", (unsigned long)n_hits);
         for (size_t i = 0; i < n_hits; i++)
-            printf("%d\t%u\t%s\n", hits[i].score, hits[i].index, db.names + db.name_off[hits[i].index]);
+            printf("%d\t%u\t%s\n", hits[i].score, hits[i].index, packed ? "" : db.names + db.name_off[hits[i].index]);
     }
     fflush(stdout);
     swg_db_free(pdb);

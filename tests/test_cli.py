@@ -104,6 +104,18 @@ def test_cli_config1_against_oracle(swg, orc, tmp_path):
     exp = orc.topk(want2.astype(np.int32), 5)
     assert top == ["%d\t%d\t%s" % (s, i, names[i]) for s, i in exp]
 
+    # makedb route: write the packed database once, search it without parsing or sorting
+    pk = tmp_path / "db.swg"
+    r2 = _run("--substitution_matrix", B62, "--savedb", str(pk), "--files", str(qf), str(df))
+    assert r2.returncode == 0 and pk.exists() and "packed database written" in r2.stderr
+    r3 = _run("--substitution_matrix", B62, "--packed", "--topk", "4", "--files", str(qf), str(pk))
+    assert r3.returncode == 0, r3.stderr
+    assert {int(m.group(1)): int(m.group(2)) for m in ENTRY_RX.finditer(r3.stdout)} == dict(enumerate(want))
+    top3 = r3.stdout.splitlines()
+    top3 = top3[top3.index("Top 4 hits (score, entry, name):") + 1:][:4]
+    assert [tuple(int(x) for x in t.split("\t")[:2]) for t in top3] == orc.topk(np.array(want, dtype=np.int32), 4)
+    assert _run("--substitution_matrix", B62, "--packed", "--printfasta", "--files", str(qf), str(pk)).returncode != 0
+
     # the multi-GPU route of the tool (one device here): same stream of entries
     r1 = _run("--substitution_matrix", B62, "--gpus", "1", "--topk", "3", "--files", str(qf), str(df))
     assert r1.returncode == 0, r1.stderr
