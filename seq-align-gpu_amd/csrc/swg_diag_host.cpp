@@ -8,9 +8,11 @@
 #include <cstring>
 #include <queue>
 
-// Measured on MI355X (profiles/r01_valu_issue_rates.txt): cycles one SIMD needs per
-// packed-int16 / DPP / v_perm wave-instruction when `wps` waves share it.
-static const double kCyclesPerInstr[5] = {0.0, 6.8, 5.3, 5.05, 4.56};
+// Cycles one SIMD needs per packed-int16 / DPP / v_perm wave-instruction when `wps` waves share
+// it.  One wave: the microbenchmark (profiles/r01_valu_issue_rates.txt).  Two to four: from the
+// fill kernel itself on a uniform database (tools/sweeps/occ.sh): three waves per SIMD are as good
+// as four, two cost 5 %; the microbenchmark's 5.3 / 5.05 / 4.56 were pessimistic.
+static const double kCyclesPerInstr[5] = {0.0, 6.8, 4.55, 4.27, 4.35};
 // ... and per instruction of a raised-priority wavefront beside three others (traced: the long
 // class advances a 4-row block of 64 x 6 columns, 296 instructions, every 1.6 us)
 static const double kHotCycles = 13.0;
@@ -48,7 +50,9 @@ uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)
 //   one lane group has to walk.  The few longest pairs can be split off into their own class
 //   (64 lanes per pair, fewest columns per lane, raised wave priority) so that (b) does not
 //   dominate small databases.
-static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 18.0 : 14.0); }
+// 10 per column pair plus the row's bookkeeping: 14 instructions, but worth about 30 issue slots
+// (DPP wait states, the wait for the row's first profile read) by the K = 16 / 24 / 32 comparison
+static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 34.0 : 30.0); }
 // one pass of several through the work queue: row index, edge hand-over to the leader, parking the
 // tail's edge
 static const double kEdgeInstr = 7.0;
@@ -219,6 +223,9 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     // fixed streams lose what the work queue was built to recover (uneven wavefront
                     // rates, a thinning tail): measured 4 900 against 5 600 GCUPS on config 2
                     if (!dynamic) cycles *= 1.15;
+                    // workgroups of more than four wavefronts measured slower than the same occupancy
+                    // from several small ones (lq 1000: 5 750 against 6 640 GCUPS)
+                    if (dynamic && W > 4) cycles *= 1.08;
                     const double ms = cycles / 2.35e9 * 1e3;
                     {
                         SwgDiagWork one;
