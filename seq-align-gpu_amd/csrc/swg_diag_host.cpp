@@ -1,6 +1,6 @@
-// swg_diag_host.cpp -- host side of the diagonal engine: geometry planning and
-// the stream layout (which pair of sequences runs in which lane group, in what
-// order).  Host-only C++ (OpenMP); no GPU needed.
+// swg_diag_host.cpp -- host side of the diagonal engine: geometry planning, the
+// pair-major token array of the work queue, and the stream layout of the fixed-stream
+// form (which pair of sequences runs in which lane group, in what order).  Host-only C++ (OpenMP); no GPU needed.
 #include "swg_host_internal.h"
 
 #include <algorithm>
@@ -53,8 +53,8 @@ uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)
 // 10 per column pair plus the row's bookkeeping: 14 instructions, but worth about 30 issue slots
 // (DPP wait states, the wait for the row's first profile read) by the K = 16 / 24 / 32 comparison
 static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 34.0 : 30.0); }
-// one pass of several through the work queue: row index, edge hand-over to the leader, parking the
-// tail's edge
+// one pass of several through the work queue: row index, edge hand-over to the leader, the tail's
+// edge store
 static const double kEdgeInstr = 7.0;
 
 // Long class: the cheapest geometry (instructions per pair-row, column padding included)
