@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--long-split", type=int, default=0, help="-1 off, 0 auto, else rows threshold of the long class")
     ap.add_argument("--long-cols", type=int, default=0, help="experiment: columns per lane of the long class")
     ap.add_argument("--static-streams", action="store_true", help="experiment: diagonal engine without the work queue")
+    ap.add_argument("--depth", type=int, default=2, help="searches in flight (1..4)")
+    ap.add_argument("--side-readout", type=int, default=-1, help="experiment: 0 = top-K and read-out on the fill stream")
     ap.add_argument("--no-long-helps", action="store_true", help="experiment: long-class lane groups do not go on with the bulk's pairs")
     ap.add_argument("--prio-share", type=int, default=-1, help="experiment: priority threshold, percent of a lane group's mean share")
     ap.add_argument("--long-group", type=int, default=0, help="experiment: lanes per pair of the long class")
@@ -126,6 +128,8 @@ def main():
     ctx.set_option("long_group", args.long_group)
     ctx.set_option("autotune", 0 if args.no_autotune else 1)
     ctx.set_option("work_queue", 0 if args.static_streams else 1)
+    if args.side_readout >= 0:
+        ctx.set_option("side_readout", args.side_readout)
     if args.no_long_helps:
         ctx.set_option("long_helps", 0)
     if args.prio_share >= 0:
@@ -139,13 +143,11 @@ def main():
     K = args.topk
     merger = TopKMerger(swg, K, rank, world, "cuda") if use_dist else None
 
-    # Steps are software-pipelined: search i+1 (and, for N > 1, i+2) is queued on the GPU before the
-    # host finishes search i (top-K read-out, and for N > 1 the all-reduce merge), so host-side work
-    # overlaps the next fill.  The fill kernels are persistent and hold every wave slot, so the
-    # all-reduce kernel of step i only gets onto the GPU when fill i+1 drains: with one more search
-    # already queued behind it the GPU does not wait for the host in that gap.  Every step still
-    # does all of its work inside the timed region.
-    depth = 1 if args.no_pipeline else (3 if use_dist else 2)
+    # Steps are software-pipelined two deep: search i+1 is queued on the GPU before the host finishes
+    # search i (top-K read-out, and for N > 1 the all-reduce merge).  The library runs a search's
+    # top-K kernels and read-out on a stream of their own, beside the start of the next fill; deeper
+    # queues measured slower.  Every step still does all of its work inside the timed region.
+    depth = 1 if args.no_pipeline else args.depth
 
     def finish(ticket):
         if use_dist:

@@ -108,7 +108,9 @@ int swg_abi_version(void);
  * "prio_share" (percent of a lane group's mean share above which a bulk pair runs at raised
  * priority; default 150), "wide16" (1 default: when the query is long enough for a score to pass
  * 32767 the diagonal engine runs its wide form, exact to 65535, and only scores beyond that are
- * re-scored in int32 | 0: plain int16 and int32 re-score from 32767). */
+ * re-scored in int32 | 0: plain int16 and int32 re-score from 32767), "side_readout" (1 default:
+ * top-K selection and read-out of a search run on their own stream, beside the fill of the search
+ * queued next). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 
 /* Replaces scoring_t for the path (reference src/alignment_scoring.h:21-37):

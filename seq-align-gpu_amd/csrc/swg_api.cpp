@@ -106,6 +106,7 @@ extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
             int least = 0, greatest = 0;
             HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
         }
         for (SwgSlot &sl : ctx->slots) {
             for (auto &ev : sl.ev) HIP_TRY(ctx, hipEventCreate(&ev));
@@ -145,6 +146,7 @@ extern "C" void swg_destroy(swg_ctx *ctx)
         (void)hipHostFree(sl.h_counters);
     }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -176,6 +178,8 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         g_swg_long_group = value;
     } else if (!strcmp(key, "autotune")) {
         ctx->opt_autotune = value != 0;
+    } else if (!strcmp(key, "side_readout")) {
+        ctx->opt_side_readout = value != 0;
     } else if (!strcmp(key, "wide16")) {
         ctx->opt_wide = value != 0;
     } else if (!strcmp(key, "long_helps")) {
@@ -1116,6 +1120,13 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[3], s));
 
+    // Top-K and read-out go to their own stream: the next search's fill is queued right behind this
+    // one's on the main stream and these small kernels run beside its start instead of holding it
+    // up (the output buffers belong to this in-flight slot until swg_search_end).
+    if (ctx->stream3 && ctx->opt_side_readout) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->cur->ev[3], 0));
+        s = ctx->stream3;
+    }
     // top-K on the device unless every score goes to the host anyway
     const bool dev_topk = k > 0 && !want_scores && k <= SWG_TOPK_CAND_CAP / 2;
     if (dev_topk)
@@ -1165,7 +1176,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->cur = S;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ctx->stream3 && ctx->opt_side_readout ? ctx->stream3 : ctx->stream; // not behind queued fills
     for (;;) { // poll: a blocking wait can cost milliseconds of wake-up latency on a busy host
         const hipError_t q = hipEventQuery(S->ev_done);
         if (q == hipSuccess) break;

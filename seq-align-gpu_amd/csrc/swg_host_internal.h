@@ -138,6 +138,7 @@ struct swg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr; // long-pair kernel runs beside the bulk kernel
+    hipStream_t stream3 = nullptr; // top-K and read-out of a finished fill, beside the next search's fill
     int n_cu = 0;
     std::string err;
     // scoring
@@ -147,7 +148,7 @@ struct swg_ctx {
     // query
     std::vector<int8_t> query;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 1, opt_wide = 1;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 1, opt_wide = 1, opt_side_readout = 1;
     // device state
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;
