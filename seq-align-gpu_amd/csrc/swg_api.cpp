@@ -800,8 +800,10 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
             best->plan[0].est_ms = ms;
         }
     }
-    // second stage: with the winning geometry, where to cut the long class off
-    if (best->n_classes == 2) {
+    // second stage: with the winning geometry, where to cut the long class off.  Fixed streams only:
+    // with the work queue the model's cut (the longest pair a fair-share wavefront still finishes
+    // within the search) is within a percent of the best measured one, less than two trials differ.
+    if (best->n_classes == 2 && !diag_class_is_dynamic(ctx, db, best->plan[0])) {
         const SwgDiagWork base = *best;
         const uint64_t n_pairs = swg_db_pair_count(db);
         const bool dyn = diag_class_is_dynamic(ctx, db, base.plan[0]);
