@@ -1336,7 +1336,7 @@ const DiagVariant *diag_variants(int *n)
     static const DiagVariant v[] = {
         make_diag<24, 16>(), make_diag<12, 16>(), make_diag<8, 16>(), make_diag<16, 16>(), make_diag<32, 12>(),
         make_diag<6, 16>(),  make_diag<10, 16>(), make_diag<20, 16>(), make_diag<28, 12>(), make_diag<4, 16>(),
-        make_diag<14, 16>(), make_diag<18, 16>(), make_diag<22, 16>(),
+        make_diag<14, 16>(), make_diag<18, 16>(), make_diag<22, 16>(), make_diag<2, 16>(),
     };
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
