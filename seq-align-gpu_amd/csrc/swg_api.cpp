@@ -137,6 +137,7 @@ extern "C" void swg_destroy(swg_ctx *ctx)
     (void)hipFree(ctx->d_profile[0]);
     (void)hipFree(ctx->d_profile[1]);
     (void)hipFree(ctx->d_profile[2]);
+    (void)hipFree(ctx->d_profile[3]);
     (void)hipFree(ctx->d_scratch);
     for (SwgSlot &sl : ctx->slots) {
         for (auto &ev : sl.ev)
@@ -384,9 +385,10 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
     return SWG_OK;
 }
 
-static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom)
+static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom, int k_real = 1,
+                               int k_padded = 1)
 {
-    const int chunk_cols = which == 2 ? 2 : 4;
+    const int chunk_cols = which == 2 ? 2 : 4; // [3]: 4-column chunks inside per-lane slices
     const size_t bytes = (size_t)ncols * 32 * elem_size;
     const uint64_t tag = (ctx->epoch << 32) ^ geom;
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
@@ -398,7 +400,7 @@ static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem
         ctx->d_profile_cap[which] = bytes;
     }
     HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols,
-                                          elem_size, chunk_cols, ctx->d_profile[which], ctx->stream));
+                                          elem_size, chunk_cols, k_real, k_padded, ctx->d_profile[which], ctx->stream));
     ctx->profile_tag[which] = tag;
     return SWG_OK;
 }
@@ -534,11 +536,12 @@ static int ensure_scratch(swg_ctx *ctx, size_t dwords)
 // ---------------------------------------------------------------------------
 // diagonal engine: make a work plan resident, launch it
 // ---------------------------------------------------------------------------
-static int diag_profile_slot(const SwgDiagPlan &pl) { return pl.K % 4 == 0 ? 0 : 2; }
+static int diag_profile_slot(const SwgDiagPlan &pl) { return pl.K % 2 ? 3 : pl.K % 4 == 0 ? 0 : 2; }
 
 static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
 {
-    uint32_t ncols[3] = {0, 0, 0};
+    uint32_t ncols[4] = {0, 0, 0, 0};
+    int odd_k = 0;
     if (ctx->opt_dynamic) {
         int rc = ensure_pair_tokens(ctx, db);
         if (rc != SWG_OK) return rc;
@@ -553,12 +556,16 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
             HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[1], bytes));
         }
         const int slot = diag_profile_slot(wk.plan[c]);
-        ncols[slot] = std::max<uint32_t>(ncols[slot], (uint32_t)(wk.plan[c].npass * wk.plan[c].G * wk.plan[c].K));
+        ncols[slot] = std::max<uint32_t>(ncols[slot], (uint32_t)(wk.plan[c].npass * wk.plan[c].G *
+                                                                 swg_diag_padded_cols(wk.plan[c].K)));
+        if (slot == 3) odd_k = wk.plan[c].K; // (the planner gives the long class an even K)
     }
     // classes with the same chunking slice the same [col/ch][32][ch] profile
-    for (int slot = 0; slot < 3; slot += 2)
-        if (ncols[slot]) {
-            int rc = ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ncols[slot]);
+    for (int slot = 0; slot < 4; ++slot)
+        if (slot != 1 && ncols[slot]) {
+            int rc = slot == 3 ? ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ((uint64_t)odd_k << 24) ^ ncols[slot],
+                                                     odd_k, swg_diag_padded_cols(odd_k))
+                               : ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ncols[slot]);
             if (rc != SWG_OK) return rc;
         }
     return SWG_OK;
@@ -624,7 +631,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.simd_ranks = db->d_counters + SWG_RANK_WORD(c);
             q.trace = d_trace[c];
             const bool edges = pl.npass > 1 || pl.wide != 0;
-            const size_t slice = (size_t)pl.G * pl.K * 64;
+            const size_t slice = (size_t)pl.G * swg_diag_padded_cols(pl.K) * 64;
             hipStream_t qs = c == 1 ? ctx->stream2 : s;
             for (int pass = 0; pass < pl.npass; ++pass) {
                 // one launch per pass: the kernel boundary is what lets any lane group take any pair

@@ -79,8 +79,9 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
         for (int gi = 0; gi < 2; ++gi) {
             const int G = groups[gi];
             if (g_swg_long_group > 0 && G != (int)g_swg_long_group) continue;
+            if (info.K % 2) continue; // the long class shares the profile buffers with the bulk: even K only
             const size_t cols = (size_t)G * info.K;
-            if (cols * 64 > 160 * 1024) continue;
+            if ((size_t)G * swg_diag_padded_cols(info.K) * 64 > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
             if (dynamic && npass > 1) continue; // the queue serves single-pass classes only
             const double instr = npass * instr_per_row(info.K, G);
@@ -92,7 +93,7 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
             c.G = G;
             c.npass = npass;
             c.W = 4;
-            c.lds_bytes = cols * 64;
+            c.lds_bytes = (size_t)G * swg_diag_padded_cols(info.K) * 64;
             if (depth <= budget_cycles && cost < best_cost) {
                 best_cost = cost;
                 fit = c;
@@ -127,7 +128,7 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
             const int G = groups[gi];
             if (opt_group > 0 && G != (int)opt_group) continue;
             const size_t cols = (size_t)G * info.K;
-            const size_t lds = cols * 64;
+            const size_t lds = (size_t)G * swg_diag_padded_cols(info.K) * 64;
             if (lds > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
             const int NG = 64 / G;

@@ -153,9 +153,10 @@ struct swg_ctx {
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;
     size_t d_query_cap = 0;
-    uint8_t *d_profile[3] = {nullptr, nullptr, nullptr}; // [0] int16, [1] int32, [2] int16 in 2-column chunks
-    size_t d_profile_cap[3] = {0, 0, 0};
-    uint64_t profile_tag[3] = {0, 0, 0}; // identifies (query, scoring, geometry) currently built
+    // [0] int16, [1] int32, [2] int16 in 2-column chunks, [3] int16 in per-lane slices of an odd K
+    uint8_t *d_profile[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t d_profile_cap[4] = {0, 0, 0, 0};
+    uint64_t profile_tag[4] = {0, 0, 0, 0}; // identifies (query, scoring, geometry) currently built
     uint64_t epoch = 1;               // bumps whenever scoring or query change
     uint32_t *d_scratch = nullptr;
     size_t d_scratch_cap = 0; // dwords

@@ -108,9 +108,12 @@ hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int wo
 // profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
 // col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.
 // chunk_cols: columns per chunk, [col/chunk][32][chunk] (4 everywhere except diagonal K % 4 == 2)
+// k_real / k_padded: a lane's slice of the diagonal engine is k_padded layout columns holding k_real
+// query columns (equal everywhere except for an odd K); ncols counts layout columns
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
-                                    uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols,
-                                    uint8_t *d_profile, hipStream_t stream);
+                                    uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols, int k_real,
+                                    int k_padded, uint8_t *d_profile, hipStream_t stream);
+int swg_diag_padded_cols(int K); // layout columns of a lane's slice
 
 // Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, or 65535 in the wide form) to list.
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling,

@@ -438,9 +438,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 template <int K, bool WIDE = false> struct CellsDiag {
     static constexpr uint32_t ZERO = WIDE ? 0x80008000u : 0u;
     DEVINL static uint32_t sub(uint32_t a, uint32_t b) { return WIDE ? pk_sub_i16_sat(a, b) : pk_sub_u16_sat(a, b); }
-    // columns per profile chunk: 4 (one ds_read_b64 per sequence) when K allows it, else 2
-    // (ds_read_b32); a chunk is [32 residues][CH] int16
-    static constexpr int CH = (K % 4 == 0) ? 4 : 2;
+    // columns per profile chunk: 4 (one ds_read_b64 per sequence), or 2 (ds_read_b32) when
+    // K = 2 mod 4; a chunk is [32 residues][CH] int16.  An odd K takes 4-column chunks and leaves
+    // the rest of its last chunk unused: a lane's slice of the profile is KP = K rounded up columns
+    // wide, the columns it works on are the first K (any K: G*K lands within G/2 columns of the
+    // query length on average instead of G).
+    static constexpr int CH = (K % 4 == 2) ? 2 : 4;
+    static constexpr int KP = (K + CH - 1) / CH * CH;
     static constexpr int CHUNK = 32 * CH * 2;
     uint32_t M[K], G[K], A[K];
     uint32_t best, mdl;
@@ -492,7 +496,7 @@ template <int K, bool WIDE = false> struct CellsDiag {
     DEVINL uint2 row(const uint8_t *prof, uint32_t offx, uint32_t offy, uint32_t em, uint32_t eb,
                      uint32_t go, uint32_t ge)
     {
-        constexpr int NCH = K / CH;
+        constexpr int NCH = KP / CH;
         uint32_t md = mdl;
         uint32_t gl = sub(em, go);
         uint32_t bl = eb;
@@ -510,6 +514,7 @@ template <int K, bool WIDE = false> struct CellsDiag {
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int k = CH * c + u;
+                if (k >= K) break; // unused tail of an odd K's last chunk
                 const uint32_t t = pk_add_i16_sat(md, s[u]);
                 md = M[k];
                 const uint32_t a = pk_max_i16(G[k], sub(A[k], ge));
@@ -566,8 +571,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
     const uint2 *tp = p.tok + boff;
     uint2 *sp = p.scratch + boff * 4u;
     constexpr int CH = CellsDiag<K>::CH;
-    const uint32_t base = (uint32_t)g * (K / CH) * CellsDiag<K>::CHUNK;
-    const uint32_t slice = (uint32_t)G * K * 64u;
+    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / CH) * CellsDiag<K>::CHUNK;
+    const uint32_t slice = (uint32_t)G * CellsDiag<K>::KP * 64u;
     const int npass = MULTIPASS ? (int)p.npass : 1;
 
     for (int pass = 0; pass < npass; ++pass) {
@@ -764,8 +769,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     const bool leader = g == 0, tail = g == G - 1;
     constexpr int CH = CellsDiag<K>::CH;
     constexpr uint32_t Z = CellsDiag<K, WIDE>::ZERO; // score 0 in the cells' representation
-    const uint32_t base = (uint32_t)g * (K / CH) * CellsDiag<K>::CHUNK;
-    const uint32_t slice = (uint32_t)G * K * 64u;
+    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / CH) * CellsDiag<K>::CHUNK;
+    const uint32_t slice = (uint32_t)G * CellsDiag<K>::KP * 64u;
     // recomputed where it is needed (rarely) instead of living in a register
     auto record = [&]() -> uint32_t * {
         const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -986,13 +991,16 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
 // small kernels
 // ---------------------------------------------------------------------------
 __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
-                                         uint32_t ncols, int elem_size, uint32_t ch, uint8_t *out)
+                                         uint32_t ncols, int elem_size, uint32_t ch, uint32_t k_real,
+                                         uint32_t k_padded, uint8_t *out)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (col, code)
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
     if (t >= ncols * 32u) return;
     const uint32_t col = t >> 5, code = t & 31u;
-    const bool pad = (col >= lq) || (code == 0u);
-    const int v = pad ? 0 : (int)sub[(int)query[col] * 32 + (int)code];
+    // a lane's slice is k_padded layout columns of which the first k_real are query columns
+    const uint32_t j = col % k_padded, qcol = (col / k_padded) * k_real + j;
+    const bool pad = (j >= k_real) || (qcol >= lq) || (code == 0u);
+    const int v = pad ? 0 : (int)sub[(int)query[qcol] * 32 + (int)code];
     const size_t e = (size_t)(col / ch) * (32u * ch) + code * ch + (col % ch); // [col/ch][32][ch]
     if (elem_size == 2)
         reinterpret_cast<int16_t *>(out)[e] = pad ? (int16_t)-32768 : (int16_t)v;
@@ -1337,6 +1345,9 @@ const DiagVariant *diag_variants(int *n)
         make_diag<24, 16>(), make_diag<12, 16>(), make_diag<8, 16>(), make_diag<16, 16>(), make_diag<32, 12>(),
         make_diag<6, 16>(),  make_diag<10, 16>(), make_diag<20, 16>(), make_diag<28, 12>(), make_diag<4, 16>(),
         make_diag<14, 16>(), make_diag<18, 16>(), make_diag<22, 16>(), make_diag<2, 16>(),
+        make_diag<23, 16>(), make_diag<21, 16>(), make_diag<19, 16>(), make_diag<17, 16>(), make_diag<15, 16>(),
+        make_diag<13, 16>(), make_diag<11, 16>(), make_diag<9, 16>(), make_diag<7, 16>(), make_diag<31, 12>(),
+        make_diag<29, 12>(), make_diag<27, 12>(), make_diag<25, 12>(),
     };
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
@@ -1372,9 +1383,11 @@ hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int wo
     return hipGetLastError();
 }
 
+int swg_diag_padded_cols(int K) { return K % 4 == 2 ? K : (K + 3) / 4 * 4; }
+
 size_t swg_diag_dyn_lds_bytes(int K, int G, int W)
 {
-    return (size_t)G * K * 64u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
+    return (size_t)G * swg_diag_padded_cols(K) * 64u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
 }
 
 hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int workgroups, const SwgDiagDynParams &p,
@@ -1437,12 +1450,12 @@ hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups, const S
 }
 
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, uint32_t lq,
-                                    uint32_t ncols, int elem_size, int chunk_cols, uint8_t *d_profile,
-                                    hipStream_t stream)
+                                    uint32_t ncols, int elem_size, int chunk_cols, int k_real, int k_padded,
+                                    uint8_t *d_profile, hipStream_t stream)
 {
     const uint32_t n = ncols * 32u;
     hipLaunchKernelGGL(swg_build_profile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_sub,
-                       d_query, lq, ncols, elem_size, (uint32_t)chunk_cols, d_profile);
+                       d_query, lq, ncols, elem_size, (uint32_t)chunk_cols, (uint32_t)k_real, (uint32_t)k_padded, d_profile);
     return hipGetLastError();
 }
 
