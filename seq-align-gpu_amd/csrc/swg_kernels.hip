@@ -1347,7 +1347,8 @@ const DiagVariant *diag_variants(int *n)
         make_diag<14, 16>(), make_diag<18, 16>(), make_diag<22, 16>(), make_diag<2, 16>(),
         make_diag<23, 16>(), make_diag<21, 16>(), make_diag<19, 16>(), make_diag<17, 16>(), make_diag<15, 16>(),
         make_diag<13, 16>(), make_diag<11, 16>(), make_diag<9, 16>(), make_diag<7, 16>(), make_diag<31, 12>(),
-        make_diag<29, 12>(), make_diag<27, 12>(), make_diag<25, 12>(),
+        make_diag<29, 12>(), make_diag<27, 12>(), make_diag<25, 12>(), make_diag<30, 12>(), make_diag<26, 12>(),
+        make_diag<5, 16>(), make_diag<3, 16>(),
     };
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;

@@ -101,7 +101,7 @@ def test_overflow_is_detected_and_rescored(swg, ctx):
                                               (6, 64, 16), (10, 32, 8), (6, 16, 4), (20, 16, 4), (28, 16, 4),
                                               (14, 16, 4), (18, 32, 8), (22, 16, 4), (4, 64, 4), (2, 64, 4), (2, 16, 4),
                                               (23, 16, 4), (21, 32, 8), (9, 64, 4), (31, 16, 4), (25, 32, 4), (7, 16, 4),
-                                              (13, 64, 8), (17, 16, 16)])
+                                              (13, 64, 8), (17, 16, 16), (3, 64, 4), (5, 32, 4), (26, 16, 4), (30, 32, 4)])
 def test_diagonal_geometry_does_not_change_scores(swg, ctx, cols, group, waves):
     """Columns per lane, lanes per sequence pair, occupancy and the number of query passes
     (1 .. 24 here) are invisible in the result of the diagonal engine."""
@@ -357,7 +357,7 @@ def test_errors_are_codes_not_crashes(swg, ctx):
     with pytest.raises(swg.SwgError) as e:
         ctx.search(db)
     assert e.value.code == swg.SWG_ERR_STATE
-    ctx.set_option("cols_per_wave", 5)                    # no such instantiation
+    ctx.set_option("cols_per_wave", 33)                   # no such instantiation
     db.upload(ctx)
     with pytest.raises(swg.SwgError):
         ctx.search(db)
