@@ -227,7 +227,8 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     // workgroups of more than four wavefronts measured slower than the same occupancy
                     // from several small ones (lq 1000: 5 750 against 6 640 GCUPS)
                     if (dynamic && W > 4) cycles *= 1.08;
-                    const double ms = cycles / 2.35e9 * 1e3;
+                    // (where a chain decides, the plans it ties are told apart by their throughput time)
+                    const double ms = (cycles + 1e-3 * work / simds) / 2.35e9 * 1e3;
                     {
                         SwgDiagWork one;
                         SwgDiagWork *wk = &one;
