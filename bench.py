@@ -64,7 +64,10 @@ def main():
     ap.add_argument("--long-group", type=int, default=0, help="experiment: lanes per pair of the long class")
     ap.add_argument("--lq", type=int, default=0, help="experiment: override the query length of the config")
     ap.add_argument("--nseq", type=int, default=0, help="experiment: override the sequence count of the config")
-    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--autotune", action="store_true",
+                    help="time the best-ranked geometries on the device at the first search (default: the cost model alone, "
+                         "so that every rank of a multi-GPU run uses the same plan)")
+    ap.add_argument("--no-autotune", action="store_true", help="(the default; kept for the sweep scripts)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queuing the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-len", type=int, default=0,
@@ -126,7 +129,7 @@ def main():
     ctx.set_option("long_split", args.long_split)
     ctx.set_option("long_cols", args.long_cols)
     ctx.set_option("long_group", args.long_group)
-    ctx.set_option("autotune", 0 if args.no_autotune else 1)
+    ctx.set_option("autotune", 1 if args.autotune and not args.no_autotune else 0)
     ctx.set_option("work_queue", 0 if args.static_streams else 1)
     if args.side_readout >= 0:
         ctx.set_option("side_readout", args.side_readout)
@@ -136,8 +139,8 @@ def main():
         ctx.set_option("prio_share", args.prio_share)
     db = swg.Database(flat, off).upload(ctx)
     residues = int(db.residues)
-    # setup, untimed like the upload: the first search of a query length plans and autotunes the
-    # kernel geometry for this database on this device
+    # setup, untimed like the upload: the first search of a query length plans the kernel geometry
+    # for this database (and with --autotune times the best-ranked plans on this device)
     ctx.search(db, want_scores=False, k=args.topk)
 
     K = args.topk
