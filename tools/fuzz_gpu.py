@@ -31,6 +31,13 @@ def main(budget=300.0, seed=1):
         go, ge = [(-2, -1), (-10, -1), (0, -1), (-3, 0), (-11, -2)][int(rng.integers(0, 5))]
         q = swg.synth_query(int(rng.integers(1, 1 << 30)), lq)
         seqs = [swg.synth_query(int(rng.integers(1, 1 << 30)), L) for L in lens]
+        if rng.random() < 0.12:   # scores beyond int16 and beyond 65535: tryptophan-rich query, copies of its prefixes
+            lq = int(rng.choice([2100, 3000, 4500]))
+            q = swg.synth_query(int(rng.integers(1, 1 << 30)), lq)
+            q[rng.random(lq) < 0.9] = 23
+            sc = swg.load_scoring("PAM250")
+            lens = [int(v) for v in rng.integers(1500, lq + 1, size=4)] + [int(v) for v in rng.integers(1, 200, size=int(rng.integers(1, 300)))]
+            seqs = [q[:L].copy() if i < 4 else swg.synth_query(int(rng.integers(1, 1 << 30)), L) for i, L in enumerate(lens)]
         if rng.random() < 0.3 and lq > 50:   # plant similar sequences
             for i in rng.integers(0, len(seqs), size=min(5, len(seqs))):
                 L = len(seqs[i]); m = min(L, lq); seqs[i][:m] = q[:m]
@@ -55,6 +62,7 @@ def main(budget=300.0, seed=1):
             opts = {"force_bits": 32}
         if rng.random() < 0.2: opts["long_helps"] = 0
         if rng.random() < 0.2: opts["autotune"] = 0
+        if rng.random() < 0.15: opts["wide16"] = 0
         if "cols_per_wave" in opts and opts["cols_per_wave"] * opts["group_lanes"] * 64 > 150 * 1024:
             opts = {}
         for k, v in opts.items(): ctx.set_option(k, v)
