@@ -612,6 +612,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.queue = db->d_counters + SWG_QUEUE_WORD(c); // zeroed with the other counters before the fill
             q.profile = ctx->d_profile[diag_profile_slot(pl)];
             q.scores = db->d_scores;
+            q.pair_limit = (uint32_t)(((size_t)db->n_bins * SWG_BIN) / 2);
             q.G = (uint32_t)pl.G;
             q.go = g | (g << 16);
             q.ge = e | (e << 16);

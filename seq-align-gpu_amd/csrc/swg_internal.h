@@ -64,6 +64,7 @@ struct SwgDiagDynParams {
     uint32_t *queue2;          // launch is serving off these counters
     const uint8_t *profile;   // [G*K/ch][32][ch] int16
     int32_t *scores;          // by sorted rank: pair p -> 2p, 2p+1
+    uint32_t pair_limit;      // pairs the score array has room for: nothing is written beyond it
     uint32_t G;
     uint32_t go, ge;          // |gap_open+gap_extend|, |gap_extend| in both halves
     uint32_t prio_blocks;     // a wavefront feeding a pair of >= this many blocks runs at raised priority

@@ -959,7 +959,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 const uint32_t popped = st[3];
                 const uint32_t pr = st[SWG_DYN_RING + (popped & (SWG_DYN_RING - 1u))];
                 st[3] = popped + 1u;
-                if (EDGES) { // one pass of several: the score is the maximum over the passes
+                if (pr >= p.pair_limit) {
+                    // cannot happen with a well-formed token stream; a stray write must not, either
+                } else if (EDGES) { // one pass of several: the score is the maximum over the passes
                     atomicMax(p.scores + 2u * pr, (int)((c_out ^ Z) & 0xFFFFu));
                     atomicMax(p.scores + 2u * pr + 1u, (int)((c_out ^ Z) >> 16));
                 } else {
