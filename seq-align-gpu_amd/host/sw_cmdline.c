@@ -45,7 +45,9 @@ static void usage(const char *argv0, const char *err)
             "    --gpus <N>           shard the database over GPUs 0..N-1 (RCCL top-K merge)\n"
             "    --savedb <file>      also write the packed database (sorted, binned, dword-packed)\n"
             "    --packed             the database file is such a packed database: no parsing,\n"
-            "                         no sorting; record names and sequences are not in it\n",
+            "                         no sorting; record names and sequences are not in it\n"
+            "    --allqueries         every record of the query file against the resident database\n"
+            "                         (one block of output per query, headed `Query #n: name`)\n",
             argv0);
     exit(EXIT_FAILURE);
 }
@@ -71,7 +73,7 @@ int main(int argc, char **argv)
     swg_scoring sc;
     swg_scoring_init(&sc);
     const char *qpath = NULL, *dbpath = NULL, *savedb = NULL;
-    int print_seq = 0, print_fasta = 0, have_matrix = 0, packed = 0;
+    int print_seq = 0, print_fasta = 0, have_matrix = 0, packed = 0, allq = 0;
     long topk = 0, gpu = 0, gpus = 0, v;
     if (argc == 1) usage(argv[0], NULL);
     for (int i = 1; i < argc; i++)
@@ -113,6 +115,8 @@ int main(int argc, char **argv)
             savedb = argv[++i];
         } else if (!strcasecmp(a, "--packed")) {
             packed = 1;
+        } else if (!strcasecmp(a, "--allqueries")) {
+            allq = 1;
         } else if (!strcasecmp(a, "--gpus")) {
             if (!parse_int(argv[i + 1], 1, 64, &gpus)) usage(argv[0], "Invalid --gpus argument");
             i++;
@@ -135,11 +139,11 @@ int main(int argc, char **argv)
     if (!qpath || !dbpath) usage(argv[0], "Both query and database files must be provided");
     if (!have_matrix) usage(argv[0], "--substitution_matrix is required (the fill scores from the matrix only)");
     if (packed && (print_seq || print_fasta)) usage(argv[0], "--printseq/--printfasta need the FASTA database, not --packed");
-    if ((packed || savedb) && gpus > 0) usage(argv[0], "--packed/--savedb work with one GPU (--gpu)");
+    if ((packed || savedb || allq) && gpus > 0) usage(argv[0], "--packed/--savedb/--allqueries work with one GPU (--gpu)");
 
     char err[512];
     swg_seqs q, db;
-    if (swg_seqs_read(qpath, 1, &q, err, sizeof err) != SWG_OK) {
+    if (swg_seqs_read(qpath, allq ? 0 : 1, &q, err, sizeof err) != SWG_OK) {
         fprintf(stderr, "Error: couldn't open query file %s\n", qpath);
         return EXIT_SUCCESS; /* the reference returns from the driver and exits 0 */
     }
@@ -234,6 +238,9 @@ int main(int argc, char **argv)
 
     /* reference src/tools/sw_cmdline.c:38-75: per 16 records the query lines, then per record */
     const char *qname = q.names + q.name_off[0];
+    size_t qi = 0;
+next_query:
+    if (allq) printf("Query #%lu: %s\n", (unsigned long)qi, qname);
     for (size_t i = 0; i < db.n; i++) {
         if (i % 16 == 0) {
             if (print_fasta) {
@@ -241,7 +248,7 @@ int main(int argc, char **argv)
                 putc('\n', stdout);
             }
             if (print_seq) {
-                fwrite(q.seq, 1, lq, stdout);
+                fwrite(q.seq + q.seq_off[qi], 1, (size_t)(q.seq_off[qi + 1] - q.seq_off[qi]), stdout);
                 putc('\n', stdout);
             }
         }
@@ -263,6 +270,34 @@ int main(int argc, char **argv)
         printf("Top %lu hits (score, entry, name):\n", (unsigned long)n_hits);
         for (size_t i = 0; i < n_hits; i++)
             printf("%d\t%u\t%s\n", hits[i].score, hits[i].index, packed ? "" : db.names + db.name_off[hits[i].index]);
+    }
+    if (allq && ++qi < q.n) {
+        /* the database stays resident: only the query (and its profile) changes */
+        const size_t lqi = (size_t)(q.seq_off[qi + 1] - q.seq_off[qi]);
+        if (lqi == 0) {
+            fprintf(stderr, "Error: query #%lu is empty\n", (unsigned long)qi);
+            return EXIT_FAILURE;
+        }
+        int8_t *qx = (int8_t *)malloc(lqi);
+        if (!qx) return EXIT_FAILURE;
+        for (size_t c = 0; c < lqi; c++) {
+            const int v = swg_letter_index((unsigned char)q.seq[q.seq_off[qi] + c]);
+            if (v < 0) die_illegal(q.seq[q.seq_off[qi] + c]);
+            qx[c] = (int8_t)v;
+        }
+        swg_query_sanitize(&sc, qx, lqi);
+        swg_stats st;
+        memset(&st, 0, sizeof st);
+        int rc = swg_set_query(ctx, qx, lqi);
+        if (rc == SWG_OK) rc = swg_search(ctx, pdb, scores, hits, (size_t)topk, &n_hits, &st);
+        free(qx);
+        if (rc != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
+            return EXIT_FAILURE;
+        }
+        total_ms = st.total_ms;
+        qname = q.names + q.name_off[qi];
+        goto next_query;
     }
     fflush(stdout);
     swg_db_free(pdb);

@@ -116,6 +116,20 @@ def test_cli_config1_against_oracle(swg, orc, tmp_path):
     assert [tuple(int(x) for x in t.split("\t")[:2]) for t in top3] == orc.topk(np.array(want, dtype=np.int32), 4)
     assert _run("--substitution_matrix", B62, "--packed", "--printfasta", "--files", str(qf), str(pk)).returncode != 0
 
+    # every record of the query file against the resident database
+    q2 = swg.synth_query(77, 61)
+    q3 = swg.synth_query(78, 300)
+    qf3 = tmp_path / "queries.fasta"
+    _write_fasta(qf3, ["query1", "second", "third one"], [_letters(swg, q), _letters(swg, q2), _letters(swg, q3)])
+    r4 = _run("--substitution_matrix", B62, "--allqueries", "--files", str(qf3), str(df))
+    assert r4.returncode == 0, r4.stderr
+    blocks = re.split(r"^Query #(\d+): (.*)$", r4.stdout, flags=re.MULTILINE)
+    assert [blocks[i] for i in (1, 4, 7)] == ["0", "1", "2"] and [blocks[i] for i in (2, 5, 8)] == ["query1", "second", "third one"]
+    for qq, text in ((q, blocks[3]), (q2, blocks[6]), (q3, blocks[9])):
+        w = [orc.pair(qq, swg.letters_to_indices(s), sc.table(), -2, -1) for s in seqs]
+        assert {int(m.group(1)): int(m.group(2)) for m in ENTRY_RX.finditer(text)} == dict(enumerate(w))
+        assert "Total Entries: %d" % len(seqs) in text
+
     # the multi-GPU route of the tool (one device here): same stream of entries
     r1 = _run("--substitution_matrix", B62, "--gpus", "1", "--topk", "3", "--files", str(qf), str(df))
     assert r1.returncode == 0, r1.stderr
