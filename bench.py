@@ -59,7 +59,8 @@ def main():
     ap.add_argument("--static-streams", action="store_true", help="experiment: diagonal engine without the work queue")
     ap.add_argument("--depth", type=int, default=2, help="searches in flight (1..4)")
     ap.add_argument("--side-readout", type=int, default=-1, help="experiment: 0 = top-K and read-out on the fill stream")
-    ap.add_argument("--no-long-helps", action="store_true", help="experiment: long-class lane groups do not go on with the bulk's pairs")
+    ap.add_argument("--long-helps", action="store_true", help="experiment: long-class lane groups go on with the bulk's pairs")
+    ap.add_argument("--no-long-helps", action="store_true", help="(the default; kept for the sweep scripts)")
     ap.add_argument("--prio-share", type=int, default=-1, help="experiment: priority threshold, percent of a lane group's mean share")
     ap.add_argument("--long-group", type=int, default=0, help="experiment: lanes per pair of the long class")
     ap.add_argument("--lq", type=int, default=0, help="experiment: override the query length of the config")
@@ -133,8 +134,8 @@ def main():
     ctx.set_option("work_queue", 0 if args.static_streams else 1)
     if args.side_readout >= 0:
         ctx.set_option("side_readout", args.side_readout)
-    if args.no_long_helps:
-        ctx.set_option("long_helps", 0)
+    if args.long_helps:
+        ctx.set_option("long_helps", 1)
     if args.prio_share >= 0:
         ctx.set_option("prio_share", args.prio_share)
     db = swg.Database(flat, off).upload(ctx)

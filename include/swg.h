@@ -104,7 +104,8 @@ int swg_abi_version(void);
  * ranks best are timed on the device and the fastest is kept for that database | 0 model only),
  * "workgroups" (0 auto), "work_queue" (1 default: single-pass diagonal fills hand pairs to lane
  * groups through device-wide counters | 0 fixed streams laid out on the host), "long_helps"
- * (1 default: lane groups of the long class go on with the bulk's pairs when their own are done),
+ * (0 default | 1: lane groups of the long class go on with the bulk's pairs when their own are
+ * done -- three wavefronts per SIMD issue as fast as four, so the less efficient helpers cost 1.5 %),
  * "prio_share" (percent of a lane group's mean share above which a bulk pair runs at raised
  * priority; default 150), "wide16" (1 default: when the query is long enough for a score to pass
  * 32767 the diagonal engine runs its wide form, exact to 65535, and only scores beyond that are

@@ -16,7 +16,8 @@ def _setup(ctx, g):
 
 
 OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups")
-DEFAULT_ON = ("work_queue", "long_helps", "wide16")
+DEFAULT_ON = ("work_queue", "wide16")
+DEFAULT_OFF = ("long_helps",)
 
 
 def _reset_options(ctx):
@@ -24,6 +25,8 @@ def _reset_options(ctx):
         ctx.set_option(k, 0)
     for k in DEFAULT_ON:
         ctx.set_option(k, 1)
+    for k in DEFAULT_OFF:
+        ctx.set_option(k, 0)
 
 
 def _truth(g):
@@ -470,7 +473,7 @@ def test_work_queue_variants_agree(swg, ctx, orc):
         off = np.zeros(len(lens) + 1, dtype=np.uint64)
         off[1:] = np.cumsum(lens)
         want = orc.score_db(q, flat, off, sc.table(), -2, -1)
-        for opts in ({}, {"work_queue": 0}, {"long_helps": 0}, {"long_split": 300}, {"long_split": 300, "long_helps": 0},
+        for opts in ({}, {"work_queue": 0}, {"long_helps": 1}, {"long_split": 300}, {"long_split": 300, "long_helps": 1},
                      {"long_split": -1}, {"cols_per_wave": 6, "group_lanes": 64, "max_waves": 4},
                      {"cols_per_wave": 12, "group_lanes": 32, "max_waves": 8, "long_split": 500},
                      {"cols_per_wave": 24, "group_lanes": 16, "max_waves": 4, "workgroups": 3}):

@@ -46,8 +46,9 @@ def main(budget=300.0, seed=1):
         ctx.set_scoring(sc, go, ge); ctx.set_query(q)
         for k in ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups"):
             ctx.set_option(k, 0)
-        for k in ("work_queue", "long_helps", "wide16", "autotune", "side_readout"):
+        for k in ("work_queue", "wide16", "autotune", "side_readout"):
             ctx.set_option(k, 1)
+        ctx.set_option("long_helps", 0)
         opts = {}
         r = rng.random()
         if r < 0.25:
@@ -60,7 +61,7 @@ def main(budget=300.0, seed=1):
             opts = {"long_split": int(rng.choice([-1, 100, 500, 2000]))}
         elif r < 0.6:
             opts = {"force_bits": 32}
-        if rng.random() < 0.2: opts["long_helps"] = 0
+        if rng.random() < 0.2: opts["long_helps"] = 1
         if rng.random() < 0.2: opts["autotune"] = 0
         if rng.random() < 0.15: opts["wide16"] = 0
         if "cols_per_wave" in opts and opts["cols_per_wave"] * opts["group_lanes"] * 64 > 150 * 1024:
