@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak: random databases (tiny to long-tailed), query lengths, scoring tables,
 gap scores and engine options through the C ABI, every score against the int32 oracle.
-usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+usage: python tests/fuzz_gpu.py [seconds] [seed]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

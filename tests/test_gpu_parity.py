@@ -587,13 +587,13 @@ def test_queries_streamed_against_resident_database(swg, ctx, orc):
 
 
 def test_randomised_soak():
-    """tools/fuzz_gpu.py for half a minute: random databases, query lengths, tables, gap scores and
+    """tests/fuzz_gpu.py for half a minute: random databases, query lengths, tables, gap scores and
     engine options through the C ABI against the int32 oracle (851 cases passed in the 7-minute run
     of round 1)."""
     import importlib.util
     import os
     from conftest import ROOT
-    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tests", "fuzz_gpu.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.main(30.0, 11) == 0
