@@ -9,10 +9,17 @@
 #include "../../include/swg_host.h"
 
 #include <ctype.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef struct {
     char *p;
@@ -63,10 +70,127 @@ void swg_seqs_free(swg_seqs *s)
     memset(s, 0, sizeof *s);
 }
 
+/* ---- plain (uncompressed) FASTA files: parsed from a memory map by all cores ---------------- */
+/* One pass over [lo, hi) of the map, which starts at a header line.  With out == NULL it only
+ * counts (records, name bytes including the terminators, residue bytes); otherwise it writes
+ * the records at the given positions.  Same rules as the line reader below: a line starting with
+ * '>' opens a record, every other non-empty line is sequence, white space inside it is dropped. */
+typedef struct {
+    size_t n, name_bytes, seq_bytes;
+} fa_count;
+
+static fa_count fa_scan(const char *d, size_t lo, size_t hi, swg_seqs *out, size_t rec, size_t npos, size_t spos)
+{
+    fa_count c = {0, 0, 0};
+    size_t p = lo;
+    while (p < hi) {
+        size_t e = p;
+        while (e < hi && d[e] != '\n') e++;
+        size_t len = e - p;
+        while (len && (d[p + len - 1] == '\r' || d[p + len - 1] == '\n')) len--;
+        if (len && d[p] == '>') {
+            if (out) {
+                out->name_off[rec + c.n] = npos + c.name_bytes;
+                out->seq_off[rec + c.n] = spos + c.seq_bytes;
+                memcpy(out->names + npos + c.name_bytes, d + p + 1, len - 1);
+                out->names[npos + c.name_bytes + len - 1] = '\0';
+            }
+            c.name_bytes += len; /* len - 1 characters and the terminator */
+            c.n++;
+        } else if (len) {
+            for (size_t i = 0; i < len; i++) {
+                const unsigned char ch = (unsigned char)d[p + i];
+                if (!isspace(ch)) {
+                    if (out) out->seq[spos + c.seq_bytes] = (char)ch;
+                    c.seq_bytes++;
+                }
+            }
+        }
+        p = e + 1;
+    }
+    return c;
+}
+
+/* 1: read; 0: not a plain FASTA file of useful size (the line reader takes it); < 0: error */
+static int read_fasta_mapped(const char *path, swg_seqs *out)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return 0;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < (1 << 20)) {
+        close(fd);
+        return 0;
+    }
+    const size_t size = (size_t)sb.st_size;
+    const char *d = (const char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (d == MAP_FAILED) return 0;
+    size_t first = 0;
+    while (first < size && isspace((unsigned char)d[first])) first++;
+    if (first >= size || d[first] != '>' || (first > 0 && d[first - 1] != '\n')) { /* gzip, FASTQ, plain lines */
+        munmap((void *)d, size);
+        return 0;
+    }
+    int T = 1;
+#ifdef _OPENMP
+    T = omp_get_max_threads();
+#endif
+    if (T > 256) T = 256;
+    size_t cut[257];
+    cut[0] = first;
+    for (int t = 1; t < T; t++) {
+        size_t p = first + (size - first) / (size_t)T * (size_t)t;
+        if (p < cut[t - 1]) p = cut[t - 1];
+        while (p < size && !(d[p] == '>' && d[p - 1] == '\n')) p++; /* next header line */
+        cut[t] = p;
+    }
+    cut[T] = size;
+    fa_count cnt[256];
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; t++) cnt[t] = fa_scan(d, cut[t], cut[t + 1], NULL, 0, 0, 0);
+    size_t n = 0, nb = 0, sbytes = 0;
+    size_t rec0[256], np0[256], sp0[256];
+    for (int t = 0; t < T; t++) {
+        rec0[t] = n;
+        np0[t] = nb;
+        sp0[t] = sbytes;
+        n += cnt[t].n;
+        nb += cnt[t].name_bytes;
+        sbytes += cnt[t].seq_bytes;
+    }
+    out->names = (char *)malloc(nb + 1);
+    out->seq = (char *)malloc(sbytes + 1);
+    out->name_off = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+    out->seq_off = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+    if (!out->names || !out->seq || !out->name_off || !out->seq_off) {
+        munmap((void *)d, size);
+        swg_seqs_free(out);
+        return SWG_ERR_NOMEM;
+    }
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; t++) (void)fa_scan(d, cut[t], cut[t + 1], out, rec0[t], np0[t], sp0[t]);
+    out->n = n;
+    out->name_off[n] = nb;
+    out->seq_off[n] = sbytes;
+    out->names[nb] = '\0';
+    out->seq[sbytes] = '\0';
+    munmap((void *)d, size);
+    return 1;
+}
+
 int swg_seqs_read(const char *path, size_t max_records, swg_seqs *out, char *err, size_t errlen)
 {
     if (!path || !out) return SWG_ERR_ARG;
     memset(out, 0, sizeof *out);
+    if (max_records == 0 && strcmp(path, "-") != 0) {
+        const int rc = read_fasta_mapped(path, out);
+        if (rc == 1) return SWG_OK;
+        if (rc < 0) {
+            if (err) snprintf(err, errlen, "out of memory reading %s", path);
+            return rc;
+        }
+        memset(out, 0, sizeof *out);
+    }
     gzFile f = strcmp(path, "-") == 0 ? gzdopen(0, "r") : gzopen(path, "r");
     if (!f) {
         if (err) snprintf(err, errlen, "couldn't open %s", path);

@@ -122,6 +122,40 @@ def test_sequence_reader(swg, tmp_path):
         swg.read_seqs(str(tmp_path / "nope.fa"))
 
 
+def test_mapped_fasta_reader_equals_line_reader(swg, tmp_path):
+    """Plain FASTA files of a megabyte or more are parsed from a memory map by all cores; the result
+    must equal the line reader's (which a gzip copy of the same bytes goes through): multi-line
+    records, CR LF line ends, blank lines, white space inside sequence lines, an empty record,
+    lower case, no newline at the end."""
+    import gzip
+    rng = np.random.default_rng(4)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdxbz*", dtype=np.uint8)
+    parts = []
+    for i in range(6000):
+        L = int(rng.integers(0, 700)) if i % 97 else 0
+        seq = letters[rng.integers(0, len(letters), size=L)].tobytes()
+        width = int(rng.integers(20, 90))
+        eol = b"\r\n" if i % 5 == 0 else b"\n"
+        parts.append(b">rec%d some text | %d" % (i, L) + eol)
+        for j in range(0, L, width):
+            line = seq[j:j + width]
+            if i % 11 == 0 and len(line) > 4:
+                line = line[:3] + b" \t" + line[3:]
+            parts.append(line + eol)
+        if i % 13 == 0:
+            parts.append(eol)
+    blob = b"\n\n" + b"".join(parts) + b">last\nACDEFGHIKL"
+    assert len(blob) > (1 << 20)
+    plain, zipped = tmp_path / "big.fa", tmp_path / "big.fa.gz"
+    plain.write_bytes(blob)
+    with gzip.open(zipped, "wb") as f:
+        f.write(blob)
+    a = swg.read_seqs(str(plain))
+    b = swg.read_seqs(str(zipped))
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert len(a[0]) == 6001 and a[0][-1] == "last" and a[1].endswith(b"ACDEFGHIKL")
+
+
 def test_pack_orders_bins_and_validates(swg):
     rng = np.random.default_rng(3)
     lens = rng.integers(1, 300, size=1000)
