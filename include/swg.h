@@ -188,6 +188,35 @@ typedef struct swg_batch16 {
 int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches,
                        double *fill_seconds);
 
+/* ---- alignments of reported hits -------------------------------------- */
+
+/* The reference reports scores only (its fork removed upstream's traceback: Final Report p.7; the
+ * comment at src/alignment.c:46 is what is left of it).  swg_align_hits re-runs the given pairs on
+ * the GPU with the recurrence of src/alignment.c:124-161 kept whole and walks back from the best
+ * match cell.  Coordinates are 0-based and half-open.  ops spells the path first to last:
+ * 'M' query residue against database residue, 'I' database residue against a gap (state A of the
+ * recurrence), 'D' query residue against a gap (state B); the path's substitution and gap scores
+ * (a gap position costs gap_extend when it continues a gap of the same kind, else
+ * gap_open + gap_extend) add up to `score`.  Ties, which the reference never had to define: the
+ * best cell is the one with the highest score, then the smallest database position, then the
+ * smallest query position; a state whose maximum is 0 starts the alignment; otherwise the first
+ * maximal predecessor in the order H, A, B. */
+typedef struct swg_alignment {
+    int32_t score;  /* recomputed here; equals the search's score for the pair */
+    uint32_t index; /* ORIGINAL database index, copied from the hit */
+    uint32_t q_begin, q_end; /* aligned part of the query */
+    uint32_t d_begin, d_end; /* aligned part of the database sequence */
+    uint32_t n_ops;          /* steps of the path (0 when the score is 0) */
+    uint32_t reserved;
+} swg_alignment;
+
+/* hits[n_hits]: only .index is read (every sequence must belong to this shard).  out[n_hits].
+ * ops: NULL, or n_hits strings of ops_stride bytes each, NUL-terminated;
+ * swg_align_ops_bound(ctx, db) = query length + longest sequence + 1 is always enough. */
+int swg_align_hits(swg_ctx *ctx, const swg_db *db, const swg_hit *hits, size_t n_hits,
+                   swg_alignment *out, char *ops, size_t ops_stride);
+size_t swg_align_ops_bound(const swg_ctx *ctx, const swg_db *db);
+
 /* ---- multi-GPU merge -------------------------------------------------- */
 
 /* 64-bit sort key of a hit: (score << 32) | (0xFFFFFFFF - index).  Larger key =

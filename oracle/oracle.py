@@ -44,6 +44,9 @@ def olib():
         _olib.sw_oracle_pair.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int, C.c_int]
         _olib.sw_oracle_pair_wrap16.restype = C.c_int32
         _olib.sw_oracle_pair_wrap16.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int, C.c_int]
+        _olib.sw_oracle_pair_trace.restype = C.c_int32
+        _olib.sw_oracle_pair_trace.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int, C.c_int,
+                                               _vp, _vp, C.c_size_t, _vp]
         _olib.sw_oracle_db.restype = None
         _olib.sw_oracle_db.argtypes = [_vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int, _vp]
         _olib.sw_oracle_letter_index.restype = C.c_int
@@ -86,6 +89,39 @@ def pair_wrap16(q, d, sub, gap_open, gap_extend):
     q, d, sub = _i8(q), _i8(d), _i8(sub).reshape(32, 32)
     return int(olib().sw_oracle_pair_wrap16(q.ctypes.data, q.size, d.ctypes.data, d.size,
                                             sub.ctypes.data, gap_open, gap_extend))
+
+
+def pair_trace(q, d, sub, gap_open, gap_extend):
+    """-> (score, (q_begin, q_end, d_begin, d_end), ops str) of one pair's alignment."""
+    q, d, sub = _i8(q), _i8(d), _i8(sub).reshape(32, 32)
+    coords = np.zeros(4, dtype=np.uint32)
+    cap = q.size + d.size + 1
+    ops = C.create_string_buffer(cap)
+    n = C.c_size_t(0)
+    sc = olib().sw_oracle_pair_trace(q.ctypes.data, q.size, d.ctypes.data, d.size, sub.ctypes.data,
+                                     gap_open, gap_extend, coords.ctypes.data, ops, cap, C.byref(n))
+    return int(sc), tuple(int(c) for c in coords), ops.value.decode()
+
+
+def path_score(q, d, sub, gap_open, gap_extend, coords, ops):
+    """Score of an alignment path under the three-state model: a residue pair scores
+    sub[q][d]; a gap position scores gap_extend when it continues a gap of the SAME kind, else
+    gap_open + gap_extend.  Checks that the path covers exactly the coordinates it reports."""
+    sub = np.asarray(sub).reshape(32, 32)
+    i, j = coords[0], coords[2]
+    total, prev = 0, ""
+    for op in ops:
+        if op == "M":
+            total += int(sub[int(q[i]), int(d[j])]); i += 1; j += 1
+        elif op == "I":
+            total += gap_extend if prev == "I" else gap_open + gap_extend; j += 1
+        elif op == "D":
+            total += gap_extend if prev == "D" else gap_open + gap_extend; i += 1
+        else:
+            raise ValueError(op)
+        prev = op
+    assert (i, j) == (coords[1], coords[3]), "path does not end where it says"
+    return total
 
 
 def score_db(q, flat, offsets, sub, gap_open, gap_extend):

@@ -81,6 +81,71 @@ int32_t sw_oracle_pair_wrap16(const int8_t *q, size_t lq, const int8_t *d,
     return best;
 }
 
+/* Alignment of one pair: the same recurrence kept whole, one byte per cell recording which
+ * predecessor each of the three states took, then a walk back from the best match cell.
+ * The reference prints scores only (its fork removed the traceback, Final Report p.7), so the
+ * PATH has no reference output to be pinned by; its score is pinned like every other (the sum of
+ * the path's substitution and gap scores equals sw_oracle_pair).  Tie rules are this build's
+ * (include/swg.h, swg_align_hits): best cell = highest H, then smallest database position, then
+ * smallest query position; a state whose maximum is 0 starts the alignment there; otherwise the
+ * first maximal predecessor in the order H, A, B. */
+int32_t sw_oracle_pair_trace(const int8_t *q, size_t lq, const int8_t *d, size_t ld,
+                             const int8_t sub[32][32], int gap_open, int gap_extend,
+                             uint32_t coords[4], char *ops, size_t ops_cap, size_t *n_ops)
+{
+    coords[0] = coords[1] = coords[2] = coords[3] = 0;
+    *n_ops = 0;
+    if (ops_cap) ops[0] = 0;
+    if (lq == 0 || ld == 0) return 0;
+    const int32_t go = gap_open + gap_extend, ge = gap_extend;
+    int32_t *buf = (int32_t *)calloc(3 * (lq + 1), sizeof(int32_t));
+    uint8_t *dir = (uint8_t *)malloc(lq * ld);
+    int32_t *H = buf, *A = buf + (lq + 1), *B = buf + 2 * (lq + 1);
+    int32_t best = 0;
+    size_t bj = 0, bi = 0;
+#define PICK(m, x, y, z) ((m) == 0 ? 0 : (x) == (m) ? 1 : (y) == (m) ? 2 : 3)
+    for (size_t j = 1; j <= ld; j++) {
+        const int dj = d[j - 1];
+        int32_t h_diag = 0, a_diag = 0, b_diag = 0, h_left = 0, a_left = 0, b_left = 0;
+        for (size_t i = 1; i <= lq; i++) {
+            const int32_t s = sub[(int)q[i - 1]][dj];
+            const int32_t h_up = H[i], a_up = A[i], b_up = B[i];
+            const int32_t mh = max2(max2(h_diag, a_diag), max2(b_diag, 0));
+            const int32_t ma = max2(max2(h_up + go, a_up + ge), max2(b_up + go, 0));
+            const int32_t mb = max2(max2(h_left + go, a_left + go), max2(b_left + ge, 0));
+            dir[(j - 1) * lq + (i - 1)] = (uint8_t)(PICK(mh, h_diag, a_diag, b_diag) |
+                                                   PICK(ma, h_up + go, a_up + ge, b_up + go) << 2 |
+                                                   PICK(mb, h_left + go, a_left + go, b_left + ge) << 4);
+            const int32_t h = mh + s;
+            if (h > best) { best = h; bj = j; bi = i; }
+            H[i] = h; A[i] = ma; B[i] = mb;
+            h_diag = h_up; a_diag = a_up; b_diag = b_up;
+            h_left = h; a_left = ma; b_left = mb;
+        }
+    }
+#undef PICK
+    size_t n = 0, j = bj, i = bi;
+    int state = 1;
+    char *rev = (char *)malloc(lq + ld + 1);
+    while (j > 0 && i > 0) {
+        const uint8_t c = dir[(j - 1) * lq + (i - 1)];
+        int p;
+        if (state == 1) { rev[n++] = 'M'; p = c & 3; j--; i--; }
+        else if (state == 2) { rev[n++] = 'I'; p = (c >> 2) & 3; j--; }
+        else { rev[n++] = 'D'; p = (c >> 4) & 3; i--; }
+        if (p == 0) break;
+        state = p;
+    }
+    coords[0] = (uint32_t)i; coords[1] = (uint32_t)bi; coords[2] = (uint32_t)j; coords[3] = (uint32_t)bj;
+    *n_ops = n;
+    if (ops_cap > n) {
+        for (size_t k = 0; k < n; k++) ops[k] = rev[n - 1 - k];
+        ops[n] = 0;
+    }
+    free(rev); free(dir); free(buf);
+    return best;
+}
+
 void sw_oracle_db(const int8_t *q, size_t lq, const int8_t *flat,
                   const uint64_t *offsets, size_t n, const int8_t sub[32][32],
                   int gap_open, int gap_extend, int32_t *scores)

@@ -30,6 +30,15 @@ extern "C" {
 int32_t sw_oracle_pair(const int8_t *q, size_t lq, const int8_t *d, size_t ld,
                        const int8_t sub[32][32], int gap_open, int gap_extend);
 
+/* The pair's alignment: score as sw_oracle_pair; coords = {query begin, query end, database begin,
+ * database end} (0-based, half-open); ops = 'M' residue pair, 'I' database residue against a gap
+ * (state A), 'D' query residue against a gap (state B), first to last, NUL-terminated when
+ * ops_cap > *n_ops.  The reference has no traceback: the path is this build's definition
+ * (tie rules in sw_oracle.c), only its score is reference-pinned. */
+int32_t sw_oracle_pair_trace(const int8_t *q, size_t lq, const int8_t *d, size_t ld,
+                             const int8_t sub[32][32], int gap_open, int gap_extend,
+                             uint32_t coords[4], char *ops, size_t ops_cap, size_t *n_ops);
+
 /* Whole database: flat residue indices + offsets[n+1]; OpenMP over pairs.
  * scores[n] in database order. */
 void sw_oracle_db(const int8_t *q, size_t lq, const int8_t *flat,

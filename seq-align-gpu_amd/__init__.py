@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_upload",
     "swg_db_free", "swg_db_save", "swg_db_load", "swg_db_count", "swg_db_total_count", "swg_db_residues",
     "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_search_begin", "swg_search_end",
-    "swg_fill_batches16", "swg_hit_key",
+    "swg_fill_batches16", "swg_align_hits", "swg_align_ops_bound", "swg_hit_key",
     "swg_key_hit", "swg_topk_merge_keys",
     "swg_group_create", "swg_group_destroy", "swg_group_size", "swg_group_last_error", "swg_group_set_option",
     "swg_group_set_scoring", "swg_group_set_query", "swg_group_load", "swg_group_search",
@@ -58,6 +58,11 @@ class Config(C.Structure):
 
 class Hit(C.Structure):
     _fields_ = [("score", C.c_int32), ("index", C.c_uint32)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("score", C.c_int32), ("index", C.c_uint32), ("q_begin", C.c_uint32), ("q_end", C.c_uint32),
+                ("d_begin", C.c_uint32), ("d_end", C.c_uint32), ("n_ops", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -123,6 +128,8 @@ _sig("swg_search", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_
 _sig("swg_search_begin", C.c_int, [_vp, _vp, C.c_int, C.c_size_t, C.POINTER(C.c_int)])
 _sig("swg_search_end", C.c_int, [_vp, C.c_int, _vp, _vp, C.POINTER(C.c_size_t), C.POINTER(Stats)])
 _sig("swg_fill_batches16", C.c_int, [_vp, C.POINTER(Batch16), C.c_size_t, C.POINTER(C.c_double)])
+_sig("swg_align_hits", C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t])
+_sig("swg_align_ops_bound", C.c_size_t, [_vp, _vp])
 _sig("swg_hit_key", C.c_uint64, [C.c_int32, C.c_uint32])
 _sig("swg_key_hit", None, [C.c_uint64, C.POINTER(Hit)])
 _sig("swg_topk_merge_keys", C.c_size_t, [_vp, C.c_size_t, C.c_size_t, _vp])
@@ -368,6 +375,26 @@ class Context:
         st = Stats()
         _check(lib.swg_search_end(self.handle, t, None, C.cast(hits, _vp), C.byref(nh), C.byref(st)), self.handle)
         return self._hit_keys(hits, k, nh.value), st.as_dict()
+
+    def align_hits(self, db, hits, want_ops=True, ops_stride=None):
+        """Alignments of the given hits [(score, index)] -> list of dicts with score, index,
+        q_begin, q_end, d_begin, d_end and (want_ops) the path as a string of M/I/D."""
+        n = len(hits)
+        arr = (Hit * max(n, 1))()
+        for i, (sc, ix) in enumerate(hits):
+            arr[i].score, arr[i].index = int(sc), int(ix)
+        out = (Alignment * max(n, 1))()
+        stride = int(ops_stride if ops_stride is not None else lib.swg_align_ops_bound(self.handle, db.handle))
+        ops = C.create_string_buffer(max(1, n * stride)) if want_ops else None
+        _check(lib.swg_align_hits(self.handle, db.handle, C.cast(arr, _vp), n, C.cast(out, _vp),
+                                  C.cast(ops, _vp) if want_ops else None, stride), self.handle)
+        res = []
+        for i in range(n):
+            a = {f: int(getattr(out[i], f)) for f, _ in Alignment._fields_ if f != "reserved"}
+            if want_ops:
+                a["ops"] = ops.raw[i * stride:i * stride + a["n_ops"]].decode()
+            res.append(a)
+        return res
 
     @staticmethod
     def _hit_keys(hits, k, n):

@@ -10,8 +10,10 @@
  *   - "Entry #n" is always the true 0-based record index (A.7-3);
  *   - the substitution matrix is mandatory and undefined pairs score 0 (A.7-1,2);
  *   - scores above 32767 are exact instead of wrapped (A.4);
- *   - --topk K appends a ranked report; --gpu N selects the device; --gpus N shards the
- *     database over devices 0..N-1 (one RCCL all-reduce merges the top-K lists).
+ *   - --topk K appends a ranked report, --align the alignments of those K (the traceback the
+ *     reference's fork removed, re-run for the reported pairs only: swg_align_hits);
+ *     --gpu N selects the device; --gpus N shards the database over devices 0..N-1 (one RCCL
+ *     all-reduce merges the top-K lists).
  * There is no CPU backend: without a GPU the tool fails with a message.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -41,6 +43,8 @@ static void usage(const char *argv0, const char *err)
             "    --printfasta         print record names\n"
             "    --printmatrices --pretty --colour --scoring <x>   accepted, no effect\n"
             "    --topk <K>           append the K best hits (score, index, name)\n"
+            "    --align              with --topk: append the alignment of every reported hit\n"
+            "                         (query line over database line, '-' = gap; coordinates 0-based, end exclusive)\n"
             "    --gpu <N>            HIP device ordinal [default: 0]\n"
             "    --gpus <N>           shard the database over GPUs 0..N-1 (RCCL top-K merge)\n"
             "    --savedb <file>      also write the packed database (sorted, binned, dword-packed)\n"
@@ -75,6 +79,7 @@ int main(int argc, char **argv)
     const char *qpath = NULL, *dbpath = NULL, *savedb = NULL;
     int print_seq = 0, print_fasta = 0, have_matrix = 0, packed = 0, allq = 0;
     long topk = 0, gpu = 0, gpus = 0, v;
+    int align = 0;
     if (argc == 1) usage(argv[0], NULL);
     for (int i = 1; i < argc; i++)
         if (!strcasecmp(argv[i], "--help") || !strcasecmp(argv[i], "-help") || !strcasecmp(argv[i], "-h"))
@@ -115,6 +120,8 @@ int main(int argc, char **argv)
             savedb = argv[++i];
         } else if (!strcasecmp(a, "--packed")) {
             packed = 1;
+        } else if (!strcasecmp(a, "--align")) {
+            align = 1;
         } else if (!strcasecmp(a, "--allqueries")) {
             allq = 1;
         } else if (!strcasecmp(a, "--gpus")) {
@@ -139,7 +146,8 @@ int main(int argc, char **argv)
     if (!qpath || !dbpath) usage(argv[0], "Both query and database files must be provided");
     if (!have_matrix) usage(argv[0], "--substitution_matrix is required (the fill scores from the matrix only)");
     if (packed && (print_seq || print_fasta)) usage(argv[0], "--printseq/--printfasta need the FASTA database, not --packed");
-    if ((packed || savedb || allq) && gpus > 0) usage(argv[0], "--packed/--savedb/--allqueries work with one GPU (--gpu)");
+    if ((packed || savedb || allq || align) && gpus > 0) usage(argv[0], "--packed/--savedb/--allqueries/--align work with one GPU (--gpu)");
+    if (align && topk == 0) usage(argv[0], "--align reports the alignments of the --topk hits: give --topk K");
 
     char err[512];
     swg_seqs q, db;
@@ -270,6 +278,38 @@ next_query:
         printf("Top %lu hits (score, entry, name):\n", (unsigned long)n_hits);
         for (size_t i = 0; i < n_hits; i++)
             printf("%d\t%u\t%s\n", hits[i].score, hits[i].index, packed ? "" : db.names + db.name_off[hits[i].index]);
+    }
+    if (align && n_hits > 0) {
+        const size_t stride = swg_align_ops_bound(ctx, pdb);
+        swg_alignment *al = (swg_alignment *)calloc(n_hits, sizeof *al);
+        char *ops = (char *)malloc(n_hits * stride);
+        char *line = (char *)malloc(stride);
+        if (!al || !ops || !line) return EXIT_FAILURE;
+        if (swg_align_hits(ctx, pdb, hits, n_hits, al, ops, stride) != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
+            return EXIT_FAILURE;
+        }
+        for (size_t i = 0; i < n_hits; i++) {
+            const swg_alignment *a = &al[i];
+            const char *o = ops + i * stride;
+            printf("Alignment #%lu: entry %u score %d query %u..%u entry %u..%u\n", (unsigned long)i, a->index,
+                   a->score, a->q_begin, a->q_end, a->d_begin, a->d_end);
+            if (packed) { /* no letters in a packed database: the path itself */
+                printf("%s\n\n", o);
+                continue;
+            }
+            const char *qs = q.seq + q.seq_off[qi] + a->q_begin, *ds = db.seq + db.seq_off[a->index] + a->d_begin;
+            size_t c = 0;
+            for (uint32_t k = 0; k < a->n_ops; k++) line[k] = o[k] == 'I' ? '-' : qs[c++];
+            line[a->n_ops] = 0;
+            printf("%s\n", line);
+            c = 0;
+            for (uint32_t k = 0; k < a->n_ops; k++) line[k] = o[k] == 'D' ? '-' : ds[c++];
+            printf("%s\n\n", line);
+        }
+        free(al);
+        free(ops);
+        free(line);
     }
     if (allq && ++qi < q.n) {
         /* the database stays resident: only the query (and its profile) changes */

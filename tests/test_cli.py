@@ -52,6 +52,8 @@ def test_cli_argument_handling(swg, tmp_path):
     assert r.returncode != 0 and "substitution matrix" in r.stderr
     r = _run("--substitution_matrix", B62, "--gapopen", "x", "--files", str(q), str(q))
     assert r.returncode != 0 and "--gapopen" in r.stderr
+    r = _run("--substitution_matrix", B62, "--align", "--files", str(q), str(q))
+    assert r.returncode != 0 and "--topk" in r.stderr
 
 
 def test_cli_refuses_without_gpu(swg, tmp_path):
@@ -104,12 +106,34 @@ def test_cli_config1_against_oracle(swg, orc, tmp_path):
     exp = orc.topk(want2.astype(np.int32), 5)
     assert top == ["%d\t%d\t%s" % (s, i, names[i]) for s, i in exp]
 
+    # alignments of the reported hits: gapped query line over gapped database line
+    ra = _run("--substitution_matrix", B62, "--gapopen", "-10", "--gapextend", "-1", "--topk", "5", "--align",
+              "--files", str(qf), str(df))
+    assert ra.returncode == 0, ra.stderr
+    al = ra.stdout.splitlines()
+    qs = _letters(swg, q)
+    for r_, (s_, i_) in enumerate(exp):
+        k = next(n for n, l in enumerate(al) if l.startswith("Alignment #%d: " % r_))
+        m = re.match(r"Alignment #\d+: entry (\d+) score (-?\d+) query (\d+)\.\.(\d+) entry (\d+)\.\.(\d+)$", al[k])
+        ent, scv, qb, qe, db_, de = (int(x) for x in m.groups())
+        assert (ent, scv) == (i_, s_)
+        top_line, bot_line = al[k + 1], al[k + 2]
+        assert len(top_line) == len(bot_line) and al[k + 3] == ""
+        assert top_line.replace("-", "") == qs[qb:qe] and bot_line.replace("-", "").upper() == seqs[i_].upper()[db_:de]
+        want_sc, co, ops = orc.pair_trace(q, swg.letters_to_indices(seqs[i_]), sc.table(), -10, -1)
+        assert (want_sc, co) == (s_, (qb, qe, db_, de))
+        assert "".join("I" if a == "-" else "D" if b == "-" else "M" for a, b in zip(top_line, bot_line)) == ops
+
     # makedb route: write the packed database once, search it without parsing or sorting
     pk = tmp_path / "db.swg"
     r2 = _run("--substitution_matrix", B62, "--savedb", str(pk), "--files", str(qf), str(df))
     assert r2.returncode == 0 and pk.exists() and "packed database written" in r2.stderr
-    r3 = _run("--substitution_matrix", B62, "--packed", "--topk", "4", "--files", str(qf), str(pk))
+    r3 = _run("--substitution_matrix", B62, "--packed", "--topk", "4", "--align", "--files", str(qf), str(pk))
     assert r3.returncode == 0, r3.stderr
+    l3 = r3.stdout.splitlines()
+    k3 = next(n for n, l in enumerate(l3) if l.startswith("Alignment #0: "))
+    best = orc.topk(np.array(want, dtype=np.int32), 1)[0][1]
+    assert l3[k3 + 1] == orc.pair_trace(q, swg.letters_to_indices(seqs[best]), sc.table(), -2, -1)[2]   # no letters: the path
     assert {int(m.group(1)): int(m.group(2)) for m in ENTRY_RX.finditer(r3.stdout)} == dict(enumerate(want))
     top3 = r3.stdout.splitlines()
     top3 = top3[top3.index("Top 4 hits (score, entry, name):") + 1:][:4]

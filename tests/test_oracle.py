@@ -83,3 +83,23 @@ def test_oracle_edge_cases(orc):
     assert orc.pair(a, np.array([18], dtype=np.int8), sub, -2, -1) == 0  # A:R = -1 -> floor 0
     assert orc.score_db(a, np.zeros(0, np.int8), np.zeros(1, np.uint64), sub, -2, -1).size == 0
     assert orc.topk(np.array([5, 9, 9, 1], dtype=np.int32), 3) == [(9, 1), (9, 2), (5, 0)]
+
+
+def test_oracle_alignment_paths_score_what_the_reference_scored(orc):
+    """sw_oracle_pair_trace: the path's substitution and gap scores add up to the score the
+    reference's own fill produced for the pair (the path itself has no reference output: the fork
+    removed the traceback), its coordinates bound the path, and it ends on a residue pair."""
+    for name in ("pam250_lq128", "blosum62_gap_10_1", "blosum62_gap_0_1", "blosum62_gap_pos1_m3", "blosum62_query_bzx",
+                 "blosum62_tiny_db", "blosum62_lq1"):
+        g = load_golden(name)
+        go, ge = int(g["gaps"][0]), int(g["gaps"][1])
+        off = g["offsets"]
+        for i in range(0, len(off) - 1, 7):
+            d = g["flat"][int(off[i]):int(off[i + 1])]
+            sc, co, ops = orc.pair_trace(g["query"], d, g["sub"], go, ge)
+            assert sc == int(g["oracle32"][i])
+            if g["ref_valid"][0]:
+                assert sc == int(g["ref16"][i])
+            assert orc.path_score(g["query"], d, g["sub"], go, ge, co, ops) == sc
+            assert (sc > 0) == (len(ops) > 0) and (not ops or ops[-1] == "M")
+            assert co[1] - co[0] == ops.count("M") + ops.count("D") and co[3] - co[2] == ops.count("M") + ops.count("I")
