@@ -465,17 +465,18 @@ static int ensure_pair_tokens(swg_ctx *ctx, swg_db *db)
     SwgPairTokens &T = db->ptok;
     if (T.tried) return SWG_OK;
     T.tried = true;
-    std::vector<uint32_t> tok;
+    std::unique_ptr<uint32_t[]> tok;
+    size_t tok_dwords = 0;
     try {
-        if (swg_build_pair_tokens(db, &tok, &T.pair_blocks_prefix) != 0) return SWG_OK; // too large: static streams
+        if (swg_build_pair_tokens(db, &tok, &tok_dwords, &T.pair_blocks_prefix) != 0) return SWG_OK; // too large: static streams
     } catch (const std::bad_alloc &) {
         return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "pair tokens: out of host memory");
     }
     T.total_blocks = T.pair_blocks_prefix.back();
-    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(8, tok.size() * 4)));
+    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(8, tok_dwords * 4)));
     HIP_TRY(ctx, hipMalloc(&T.d_pair_off, T.pair_blocks_prefix.size() * 4));
-    if (!tok.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(T.d_tok, tok.data(), tok.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (tok_dwords)
+        HIP_TRY(ctx, hipMemcpyAsync(T.d_tok, tok.get(), tok_dwords * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(T.d_pair_off, T.pair_blocks_prefix.data(), T.pair_blocks_prefix.size() * 4,
                                 hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -277,7 +277,7 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
 }
 
 // Tokens of one pair of sequences (two reset rows, then one row per residue of the longer
-// one); returns the number of 4-row blocks.  `t` must be zero-filled.
+// one, the last block filled up with padding rows); returns the number of 4-row blocks.
 static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint16_t *t)
 {
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
@@ -288,9 +288,14 @@ static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint16_t *t)
     const uint8_t *cy = has_y ? db->codes.data() + db->code_off[2 * p + 1] : nullptr;
     t[0] = 1; // reset rows: flag bit0, padding residue for both sequences
     t[1] = 1;
-    for (uint32_t j = 0; j < lx; ++j)
-        t[2 + j] = (uint16_t)(cx[j] | (j + 1 == lx ? 2u : 0u) | (j < ly ? (uint32_t)cy[j] << 8 : 0u));
-    return (2ull + lx + 3) / 4;
+    uint16_t *r = t + 2;
+    const uint32_t both = std::min(lx, ly); // (= ly: sorted order)
+    for (uint32_t j = 0; j < both; ++j) r[j] = (uint16_t)(cx[j] | (uint32_t)cy[j] << 8);
+    for (uint32_t j = both; j < lx; ++j) r[j] = cx[j];
+    if (lx) r[lx - 1] |= 2u; // last row of the pair
+    const uint64_t blocks = (2ull + lx + 3) / 4;
+    for (uint64_t j = 2ull + lx; j < blocks * 4; ++j) t[j] = 0; // rest of the last block: padding rows
+    return blocks;
 }
 
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
@@ -360,8 +365,10 @@ void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_
     }
 }
 
-int swg_build_pair_tokens(const swg_db *db, std::vector<uint32_t> *tok, std::vector<uint32_t> *pair_off)
+int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, size_t *tok_dwords,
+                          std::vector<uint32_t> *pair_off)
 {
+    *tok_dwords = 0;
     const uint64_t n_pairs = swg_db_pair_count(db);
     if (n_pairs >= (1ull << 31)) return -1;
     pair_off->assign((size_t)n_pairs + 1, 0u);
@@ -371,8 +378,11 @@ int swg_build_pair_tokens(const swg_db *db, std::vector<uint32_t> *tok, std::vec
         if (total >= (1ull << 32)) return -1; // block offsets are 32-bit on the device
         (*pair_off)[p + 1] = (uint32_t)total;
     }
-    tok->assign((size_t)total * 2, 0u);
-    uint16_t *base = reinterpret_cast<uint16_t *>(tok->data());
+    // every pair writes all rows of its blocks, so the buffer needs no zero fill: its pages are
+    // first touched by the threads that fill them
+    tok->reset(new uint32_t[std::max<size_t>(2, (size_t)total * 2)]);
+    *tok_dwords = (size_t)total * 2;
+    uint16_t *base = reinterpret_cast<uint16_t *>(tok->get());
 #pragma omp parallel for schedule(dynamic, 64)
     for (long long p = 0; p < (long long)n_pairs; ++p)
         write_pair_tokens(db, (size_t)p, base + (size_t)(*pair_off)[p] * 4);

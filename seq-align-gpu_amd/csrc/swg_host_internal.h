@@ -5,6 +5,7 @@
 #include "swg_internal.h"
 
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -180,7 +181,8 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                              long opt_long_split, bool allow_split, bool work_queue,
                              std::vector<SwgDiagWork> *cands);
 // 0 on success; -1 when the database is too large for 32-bit block offsets
-int swg_build_pair_tokens(const swg_db *db, std::vector<uint32_t> *tok, std::vector<uint32_t> *pair_off);
+int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, size_t *tok_dwords,
+                          std::vector<uint32_t> *pair_off);
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
                            uint32_t streams_per_wg, SwgDiagLayout *out);
 uint64_t swg_db_pair_count(const swg_db *db);
