@@ -294,7 +294,7 @@ def host_inclusive(swg, ctx, flat, off, k, cells):
             "upload_bytes": nbytes, "first_search_ms": round((t3 - t2) * 1e3, 3),
             "next_search_ms": round((t4 - t3) * 1e3, 3),
             "gcups_upload_and_first_search": round(cells / (t3 - t1) / 1e9, 1),
-            "note": "first search of a database builds its pair tokens on the device; all scores are copied back"}
+            "note": "the first search of a database builds its pair tokens on the host and uploads them; all scores are copied back"}
 
 
 class TopKMerger:
