@@ -126,7 +126,7 @@ static int read_fasta_mapped(const char *path, swg_seqs *out)
     close(fd);
     if (d == MAP_FAILED) return 0;
     size_t first = 0;
-    while (first < size && isspace((unsigned char)d[first])) first++;
+    while (first < size && (d[first] == '\n' || d[first] == '\r')) first++; /* empty lines, as the line reader skips them */
     if (first >= size || d[first] != '>' || (first > 0 && d[first - 1] != '\n')) { /* gzip, FASTQ, plain lines */
         munmap((void *)d, size);
         return 0;

@@ -154,6 +154,21 @@ def test_mapped_fasta_reader_equals_line_reader(swg, tmp_path):
     b = swg.read_seqs(str(zipped))
     assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     assert len(a[0]) == 6001 and a[0][-1] == "last" and a[1].endswith(b"ACDEFGHIKL")
+    # odd shapes of a megabyte or more: both readers must still agree record for record
+    big = 1 << 20
+    odd = {
+        "headers_only": b">\n" * big, "one_line": b">" + b"A" * (2 * big), "header_last": b">a\n" + b"ACDE\n" * big + b">last",
+        "crlf_blank": (b">r\r\n\r\nAC DE\r\n\r\n") * (big // 8), "header_at_end": b">a\n" + b"ACDEFGHIKL\n" * (big // 8) + b">z\n",
+        "leading_blank": b"\n \n>a\n" + b"ACDEFGHIKL\n" * (big // 8), "leading_empty": b"\n\r\n>a\n" + b"ACDEFGHIKL\n" * (big // 8),
+        "plain_lines": b"ACDEFGHIKL\n" * (big // 8),
+    }
+    for name, data in odd.items():
+        p, z = tmp_path / name, tmp_path / (name + ".gz")
+        p.write_bytes(data)
+        with gzip.open(z, "wb", compresslevel=1) as f:
+            f.write(data)
+        a, b = swg.read_seqs(str(p)), swg.read_seqs(str(z))
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[3], b[3]), name
 
 
 def test_pack_orders_bins_and_validates(swg):

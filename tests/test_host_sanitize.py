@@ -64,6 +64,14 @@ def test_host_helpers_under_asan_ubsan(tmp_path):
         "crlf": b">a\r\nAC\r\nGT\r\n", "huge_num": b"  A C\nA 99999999999999999999 1\n", "sep": b",A,C\nA,1\nC,,\n",
         "gz_garbage": b"\x1f\x8b\x08\x00garbage",
     }
+    # a megabyte or more and a '>' first: these go through the memory-mapped parallel reader
+    big = 1 << 20
+    hostile.update({
+        "big_headers_only": b">\n" * big, "big_one_line": b">" + b"A" * (2 * big), "big_no_final_newline": b">a\n" + b"ACDE\n" * big + b">last",
+        "big_binary": b">x\n" + bytes(range(256)) * (big // 128), "big_crlf_blank": (b">r\r\n\r\nAC DE\r\n\r\n") * (big // 8),
+        "big_gt_inside": b">a\n" + b"AC>DE\n>\n\n" * (big // 4), "big_header_at_end": b">a\n" + b"ACDEFGHIKL\n" * (big // 8) + b">z\n",
+        "big_leading_blank": b"\n \n>a\n" + b"ACDEFGHIKL\n" * (big // 8), "big_not_fasta": b"ACDEFGHIKL\n" * (big // 8),
+    })
     for name, data in hostile.items():
         p = tmp_path / name
         p.write_bytes(data)
