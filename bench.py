@@ -348,13 +348,23 @@ def cpu_baseline(swg, q, flat, off, sc, lq):
             seqs = [flat[int(off[i]):int(off[i + 1])] for i in range(g * 16, g * 16 + 16)]
             batches.append(orc.make_batch16(seqs))
             cells += lq * int(lens[g * 16:g * 16 + 16].sum())
-        threads = orc.rlib().swref_max_threads()
+        # The reference takes omp_get_max_threads() threads (src/alignment_cmdline.c:341-347): all
+        # hardware threads of the host.  This process may own fewer CPUs (cgroup quota, cpuset), so it is
+        # timed with that many threads too and the better rate is the baseline.
+        hw = int(orc.rlib().swref_max_threads())
+        share = int(swg.lib.swg_host_threads())
         orc.ref_batches(q, batches[:min(len(batches), 64)], table, -2, -1)      # warm the pages
-        _, secs = orc.ref_batches(q, batches, table, -2, -1)
-        return {"value": round(cells / secs / 1e9, 3), "unit": "GCUPS", "cores": int(threads), "kind": "reference",
+        runs = {}
+        for t in sorted({hw, min(hw, share)}):
+            _, secs = orc.ref_batches(q, batches, table, -2, -1, threads=t)
+            runs[t] = cells / secs / 1e9
+        best = max(runs, key=runs.get)
+        return {"value": round(runs[best], 3), "unit": "GCUPS", "cores": int(best), "kind": "reference",
                 "sample": "%d of %d 16-record batches of the same DB (%.3g real cells), reference "
-                          "alignment_fill_matrices under its OpenMP dynamic dispatch, fill region only"
-                          % (len(batches), groups, cells)}
+                          "alignment_fill_matrices under its OpenMP dynamic dispatch, fill region only; "
+                          "this process may use %d CPUs of the host's %d hardware threads; GCUPS by threads: %s"
+                          % (len(batches), groups, cells, share, hw,
+                             ", ".join("%d: %.1f" % (t, v) for t, v in sorted(runs.items())))}
     # no reference build on this box: time the scalar oracle instead (a port, much slower)
     idx = np.concatenate([np.arange(g * 16, g * 16 + 16) for g in sel[:max(1, len(sel) // 16)]])
     sub_off = np.zeros(len(idx) + 1, dtype=np.uint64)

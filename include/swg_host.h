@@ -84,6 +84,11 @@ int swg_synth_db_similar(uint64_t seed, size_t n, double median, double sigma_ln
                          double subst, int8_t **flat_out, uint64_t **offsets_out, size_t *n_planted);
 void swg_synth_free(void *p);
 
+/* Threads the host helpers' parallel loops use: the smallest of OpenMP's maximum (OMP_NUM_THREADS),
+ * the CPUs this process may run on, and its cgroup CPU quota.  (The reference sizes its loop by
+ * omp_get_max_threads() alone, src/alignment_cmdline.c:341-347.) */
+int swg_host_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
     "swg_scoring_load_matrix", "swg_query_sanitize", "swg_seqs_read", "swg_seqs_free",
     "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar",
-    "swg_synth_free",
+    "swg_synth_free", "swg_host_threads",
 ]
 
 

@@ -31,7 +31,7 @@ DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 
 HIP_SOURCES = ["swg_kernels.hip", "swg_trace.hip", "swg_api.cpp", "swg_group.cpp"]
 CXX_SOURCES = ["swg_pack.cpp", "swg_diag_host.cpp"]  # host-only C++, OpenMP via g++
-C_SOURCES = ["swg_scoring.c", "swg_seqio.c", "swg_synth.c"]
+C_SOURCES = ["swg_scoring.c", "swg_seqio.c", "swg_synth.c", "swg_threads.c"]
 CLI_SOURCES = ["sw_cmdline.c"]
 
 

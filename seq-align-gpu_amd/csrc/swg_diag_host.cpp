@@ -2,6 +2,7 @@
 // pair-major token array of the work queue, and the stream layout of the fixed-stream
 // form (which pair of sequences runs in which lane group, in what order).  Host-only C++ (OpenMP); no GPU needed.
 #include "swg_host_internal.h"
+#include "../../include/swg_host.h"
 
 #include <algorithm>
 #include <cmath>
@@ -357,7 +358,7 @@ void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_
     L->pair_rows_total = rows_total;
     L->tok.assign(L->total_blocks * 2, 0u);
     uint16_t *base = reinterpret_cast<uint16_t *>(L->tok.data()); // one 16-bit token per row
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(swg_host_threads())
     for (long long s = 0; s < (long long)n_streams; ++s) {
         uint16_t *t = base + L->stream_off[s] * 4;
         for (uint32_t i = L->stream_pair_off[s]; i < L->stream_pair_off[s + 1]; ++i)
@@ -383,7 +384,7 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
     tok->reset(new uint32_t[std::max<size_t>(2, (size_t)total * 2)]);
     *tok_dwords = (size_t)total * 2;
     uint16_t *base = reinterpret_cast<uint16_t *>(tok->get());
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(swg_host_threads())
     for (long long p = 0; p < (long long)n_pairs; ++p)
         write_pair_tokens(db, (size_t)p, base + (size_t)(*pair_off)[p] * 4);
     return 0;

@@ -7,6 +7,7 @@
 // cut into bins of 128 sequences and stored row-block-major, one dword per four
 // residues per sequence, padding = residue 0.
 #include "swg_host_internal.h"
+#include "../../include/swg_host.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -41,7 +42,7 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
     const uint64_t total = n ? offsets[n] - offsets[0] : 0;
     {
         int bad = 0;
-#pragma omp parallel for schedule(static) reduction(| : bad)
+#pragma omp parallel for schedule(static) reduction(| : bad) num_threads(swg_host_threads())
         for (long long i = (long long)offsets[0]; i < (long long)(offsets[0] + total); ++i) {
             const int v = flat[i];
             bad |= (v < 1 || v > 31);
@@ -117,7 +118,7 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
     }
 
     uint32_t *pk = db->packed.data();
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(swg_host_threads())
     for (long long lb = 0; lb < (long long)nb; ++lb) {
         uint32_t *base = pk + db->bin_off[lb];
         for (size_t s = 0; s < SWG_BIN; ++s) {

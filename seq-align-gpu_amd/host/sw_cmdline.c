@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <time.h>
 
 static void usage(const char *argv0, const char *err)
 {
@@ -45,6 +46,7 @@ static void usage(const char *argv0, const char *err)
             "    --topk <K>           append the K best hits (score, index, name)\n"
             "    --align              with --topk: append the alignment of every reported hit\n"
             "                         (query line over database line, '-' = gap; coordinates 0-based, end exclusive)\n"
+            "    --timing             wall time of every phase (reading, packing, upload, search, printing) on stderr\n"
             "    --gpu <N>            HIP device ordinal [default: 0]\n"
             "    --gpus <N>           shard the database over GPUs 0..N-1 (RCCL top-K merge)\n"
             "    --savedb <file>      also write the packed database (sorted, binned, dword-packed)\n"
@@ -54,6 +56,23 @@ static void usage(const char *argv0, const char *err)
             "                         (one block of output per query, headed `Query #n: name`)\n",
             argv0);
     exit(EXIT_FAILURE);
+}
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* --timing: wall time of the phases the reference leaves out of its `Total Time`, on stderr */
+static int timing = 0;
+static double phase_t0;
+static void phase(const char *what)
+{
+    const double t = now_ms();
+    if (timing) fprintf(stderr, "[timing] %-28s %9.2f ms\n", what, t - phase_t0);
+    phase_t0 = t;
 }
 
 static int parse_int(const char *s, long lo, long hi, long *out)
@@ -122,6 +141,8 @@ int main(int argc, char **argv)
             packed = 1;
         } else if (!strcasecmp(a, "--align")) {
             align = 1;
+        } else if (!strcasecmp(a, "--timing")) {
+            timing = 1;
         } else if (!strcasecmp(a, "--allqueries")) {
             allq = 1;
         } else if (!strcasecmp(a, "--gpus")) {
@@ -151,6 +172,7 @@ int main(int argc, char **argv)
 
     char err[512];
     swg_seqs q, db;
+    phase_t0 = now_ms();
     if (swg_seqs_read(qpath, allq ? 0 : 1, &q, err, sizeof err) != SWG_OK) {
         fprintf(stderr, "Error: couldn't open query file %s\n", qpath);
         return EXIT_SUCCESS; /* the reference returns from the driver and exits 0 */
@@ -171,6 +193,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "Error: couldn't open database file %s\n", dbpath);
         return EXIT_SUCCESS;
     }
+    phase(packed ? "read query, load packed db" : "read query and database");
     const size_t lq = (size_t)q.seq_off[1];
     int8_t *qidx = (int8_t *)malloc(lq);
     int8_t *didx = (int8_t *)malloc(db.n && !packed ? (size_t)db.seq_off[db.n] + 1 : 1);
@@ -187,6 +210,7 @@ int main(int argc, char **argv)
     swg_query_sanitize(&sc, qidx, lq); /* reference src/alignment_cmdline.c:391-396 */
     if (!packed && swg_seqs_to_indices(&db, didx, &bad) != SWG_OK) die_illegal(bad);
 
+    phase("letters to table indices");
     int32_t *scores = (int32_t *)calloc(db.n ? db.n : 1, sizeof(int32_t));
     swg_hit *hits = (swg_hit *)calloc(topk ? (size_t)topk : 1, sizeof(swg_hit));
     size_t n_hits = 0;
@@ -201,10 +225,15 @@ int main(int argc, char **argv)
             fprintf(stderr, "Error: %s\n", swg_global_error());
             return EXIT_FAILURE;
         }
-        rc = swg_group_set_scoring(grp, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
+        phase("create contexts");
+        /* one search per query length: timing candidate geometries first would cost more than it saves */
+        rc = swg_group_set_option(grp, "autotune", 0);
+        if (rc == SWG_OK) rc = swg_group_set_scoring(grp, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
         if (rc == SWG_OK) rc = swg_group_set_query(grp, qidx, lq);
         if (rc == SWG_OK) rc = swg_group_load(grp, didx, db.seq_off, db.n);
+        phase("pack, shard and upload");
         if (rc == SWG_OK) rc = swg_group_search(grp, scores, hits, (size_t)topk, &n_hits, st);
+        phase("search");
         if (rc != SWG_OK) {
             fprintf(stderr, "Error: %s\n", swg_group_last_error(grp));
             return EXIT_FAILURE;
@@ -220,13 +249,17 @@ int main(int argc, char **argv)
             fprintf(stderr, "Error: %s\n", swg_global_error());
             return EXIT_FAILURE;
         }
+        phase("create context");
         swg_stats st;
         memset(&st, 0, sizeof st);
-        int rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
+        /* one search per query length: timing candidate geometries first would cost more than it saves */
+        int rc = swg_set_option(ctx, "autotune", 0);
+        if (rc == SWG_OK) rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
         if (rc == SWG_OK) rc = swg_set_query(ctx, qidx, lq);
         if (rc == SWG_OK && !packed) {
             rc = swg_db_pack(didx, db.seq_off, db.n, 0, 1, &pdb);
             if (rc != SWG_OK) fprintf(stderr, "Error: %s\n", swg_global_error());
+            phase("sort and pack");
         }
         if (rc == SWG_OK && savedb) {
             if (swg_db_save(pdb, savedb) != SWG_OK) {
@@ -236,7 +269,9 @@ int main(int argc, char **argv)
             fprintf(stderr, "packed database written to %s\n", savedb);
         }
         if (rc == SWG_OK) rc = swg_db_upload(ctx, pdb);
+        phase("upload");
         if (rc == SWG_OK) rc = swg_search(ctx, pdb, scores, hits, (size_t)topk, &n_hits, &st);
+        phase("search (first of this database)");
         if (rc != SWG_OK) {
             fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
             return EXIT_FAILURE;
@@ -340,6 +375,7 @@ next_query:
         goto next_query;
     }
     fflush(stdout);
+    phase("print");
     swg_db_free(pdb);
     swg_destroy(ctx);
     swg_group_destroy(grp);

@@ -131,10 +131,7 @@ static int read_fasta_mapped(const char *path, swg_seqs *out)
         munmap((void *)d, size);
         return 0;
     }
-    int T = 1;
-#ifdef _OPENMP
-    T = omp_get_max_threads();
-#endif
+    int T = swg_host_threads();
     if (T > 256) T = 256;
     size_t cut[257];
     cut[0] = first;
@@ -146,7 +143,7 @@ static int read_fasta_mapped(const char *path, swg_seqs *out)
     }
     cut[T] = size;
     fa_count cnt[256];
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swg_host_threads())
     for (int t = 0; t < T; t++) cnt[t] = fa_scan(d, cut[t], cut[t + 1], NULL, 0, 0, 0);
     size_t n = 0, nb = 0, sbytes = 0;
     size_t rec0[256], np0[256], sp0[256];
@@ -167,7 +164,7 @@ static int read_fasta_mapped(const char *path, swg_seqs *out)
         swg_seqs_free(out);
         return SWG_ERR_NOMEM;
     }
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swg_host_threads())
     for (int t = 0; t < T; t++) (void)fa_scan(d, cut[t], cut[t + 1], out, rec0[t], np0[t], sp0[t]);
     out->n = n;
     out->name_off[n] = nb;
@@ -296,7 +293,7 @@ int swg_seqs_to_indices(const swg_seqs *s, int8_t *out, char *bad)
     int8_t lut[256];
     for (int c = 0; c < 256; c++) lut[c] = (int8_t)swg_letter_index(c);
     int64_t first_bad = -1;
-#pragma omp parallel for schedule(static) reduction(max : first_bad)
+#pragma omp parallel for schedule(static) reduction(max : first_bad) num_threads(swg_host_threads())
     for (int64_t blk = 0; blk < (int64_t)((total + 65535) / 65536); blk++) {
         const uint64_t lo = (uint64_t)blk * 65536, hi = lo + 65536 < total ? lo + 65536 : total;
         int8_t any = 0;

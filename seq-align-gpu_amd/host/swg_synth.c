@@ -153,7 +153,7 @@ static int synth_impl(uint64_t seed, size_t n, double median, double sigma_ln, u
         return SWG_ERR_NOMEM;
     }
     const uint64_t sub_thr = (uint64_t)(subst * 65536.0);
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(swg_host_threads())
     for (long long k = 0; k < (long long)n; k++) {
         int8_t *dst = flat + off[k];
         const uint64_t s0 = mix(seed ^ 0x5EEDu, (uint64_t)k);

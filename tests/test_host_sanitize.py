@@ -52,7 +52,7 @@ def test_host_helpers_under_asan_ubsan(tmp_path):
     host = os.path.join(ROOT, "seq-align-gpu_amd", "host")
     cmd = ["gcc", "-std=c11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fopenmp",
            "-I" + os.path.join(ROOT, "include"), "-o", str(exe), str(src)] + \
-          [os.path.join(host, f) for f in ("swg_scoring.c", "swg_seqio.c", "swg_synth.c")] + ["-lz", "-lm"]
+          [os.path.join(host, f) for f in ("swg_scoring.c", "swg_seqio.c", "swg_synth.c", "swg_threads.c")] + ["-lz", "-lm"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0 and "sanitize" in r.stdout:
         pytest.skip("sanitizer runtime not available: " + r.stdout[:200])
