@@ -24,6 +24,11 @@ import time
 # that share a queue serialise (measured: the top-K all-reduce waits behind a whole fill and the
 # step grows by 0.4 ms).  Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Several ranks on one node share its CPUs: without a setting (torchrun exports OMP_NUM_THREADS=1 by
+# itself) every rank's host loops would take the whole machine.  Setup work only (packing a shard).
+if int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) > 1:
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 16) //
+                          int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))))
 
 import numpy as np  # noqa: E402
 
