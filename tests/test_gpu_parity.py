@@ -424,6 +424,44 @@ def test_full_size_config2_properties(swg, ctx, orc):
     db.close()
 
 
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config4_share"])
+def test_full_size_databases_equal_the_reference_itself(swg, ctx, orc, cfg):
+    """BASELINE configs 2 and 3 at full size, and one GPU's eighth of config 4, score for score against
+    the REFERENCE's own alignment_fill_matrices (oracle/_ref: its alignment.c compiled from its
+    sources, run under its OpenMP dispatch on the host; config 4: every 8th 16-record batch, the GPU
+    still searches all 1.25 million sequences).  The synthetic databases are emitted sorted by
+    length and in multiples of 16, which is what the reference's packer requires."""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref was not built (needs the reference sources at build time)")
+    lq, n, mat, seed, every = {"config2": (367, 100000, "PAM250", 0x5EED0002, 1),
+                               "config3": (500, 570000, "BLOSUM62", 0x5EED0003, 1),
+                               "config4_share": (3000, 1250000, "BLOSUM62", 0x5EED0004, 8)}[cfg]
+    sc = swg.load_scoring(mat)
+    tab = sc.table()
+    q = swg.synth_query(seed, lq)
+    flat, off = swg.synth_db(seed, n)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    db = swg.Database(flat, off).upload(ctx)
+    scores, _, st = ctx.search(db)
+    db.close()
+    assert st["engine"] == 2 and st["path_bits"] == 16 and st["n_rescored"] == 0
+    groups = np.arange(0, n // 16, every)
+    lens = np.diff(off.astype(np.int64))
+    assert all(lens[g * 16] == lens[g * 16:g * 16 + 16].max() for g in groups[:: max(1, len(groups) // 2000)])
+    batches = []
+    for g in groups:
+        o = off[g * 16:g * 16 + 17].astype(np.int64)
+        b = np.full((int(o[1] - o[0]), 16), 31, dtype=np.int8)          # '*' filler, src/alignment_cmdline.c:444-450
+        for l in range(16):
+            b[:int(o[l + 1] - o[l]), l] = flat[int(o[l]):int(o[l + 1])]
+        batches.append(b)
+    ref, _ = orc.ref_batches(q, batches, tab, -2, -1, threads=int(swg.lib.swg_host_threads()))
+    idx = (groups[:, None] * 16 + np.arange(16)[None, :]).ravel()
+    assert np.array_equal(ref.astype(np.int32).ravel(), scores[idx]), cfg
+
+
 def test_long_tail_database(swg, ctx, orc):
     """Swiss-Prot-like tail: a 35,000-residue sequence among short ones (one very long pair,
     odd sequence count, lengths 1 and 2 present), query longer than one pass of some geometries."""
