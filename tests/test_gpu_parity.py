@@ -424,29 +424,37 @@ def test_full_size_config2_properties(swg, ctx, orc):
     db.close()
 
 
-@pytest.mark.parametrize("cfg", ["config2", "config3", "config4_share"])
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config4_share", "config5"])
 def test_full_size_databases_equal_the_reference_itself(swg, ctx, orc, cfg):
     """BASELINE configs 2 and 3 at full size, and one GPU's eighth of config 4, score for score against
     the REFERENCE's own alignment_fill_matrices (oracle/_ref: its alignment.c compiled from its
     sources, run under its OpenMP dispatch on the host; config 4: every 8th 16-record batch, the GPU
-    still searches all 1.25 million sequences).  The synthetic databases are emitted sorted by
-    length and in multiples of 16, which is what the reference's packer requires."""
+    still searches all 1.25 million sequences).  Config 5 (8192-aa query, 1 % near-copies scoring
+    about 40 000): the reference's int16 lanes wrap above 32767, so every sequence the
+    GPU scores at most 32767 must equal the reference and every third of the others the int32 oracle.
+    The synthetic databases are emitted sorted by length and in multiples of 16, which is what the
+    reference's packer requires."""
     if not orc.have_ref():
         pytest.skip("oracle/_ref was not built (needs the reference sources at build time)")
     lq, n, mat, seed, every = {"config2": (367, 100000, "PAM250", 0x5EED0002, 1),
                                "config3": (500, 570000, "BLOSUM62", 0x5EED0003, 1),
-                               "config4_share": (3000, 1250000, "BLOSUM62", 0x5EED0004, 8)}[cfg]
+                               "config4_share": (3000, 1250000, "BLOSUM62", 0x5EED0004, 8),
+                               "config5": (8192, 100000, "BLOSUM62", 0x5EED0005, 1)}[cfg]
     sc = swg.load_scoring(mat)
     tab = sc.table()
     q = swg.synth_query(seed, lq)
-    flat, off = swg.synth_db(seed, n)
+    if cfg == "config5":
+        flat, off, planted = swg.synth_db(seed, n, query=q, fraction=0.01, subst=0.05)
+        assert planted > 0
+    else:
+        flat, off = swg.synth_db(seed, n)
     ctx.set_scoring(sc, -2, -1)
     ctx.set_query(q)
     _reset_options(ctx)
     db = swg.Database(flat, off).upload(ctx)
     scores, _, st = ctx.search(db)
     db.close()
-    assert st["engine"] == 2 and st["path_bits"] == 16 and st["n_rescored"] == 0
+    assert st["engine"] == 2 and st["path_bits"] == 16 and (st["n_rescored"] == 0 or cfg == "config5")
     groups = np.arange(0, n // 16, every)
     lens = np.diff(off.astype(np.int64))
     assert all(lens[g * 16] == lens[g * 16:g * 16 + 16].max() for g in groups[:: max(1, len(groups) // 2000)])
@@ -459,7 +467,18 @@ def test_full_size_databases_equal_the_reference_itself(swg, ctx, orc, cfg):
         batches.append(b)
     ref, _ = orc.ref_batches(q, batches, tab, -2, -1, threads=int(swg.lib.swg_host_threads()))
     idx = (groups[:, None] * 16 + np.arange(16)[None, :]).ravel()
-    assert np.array_equal(ref.astype(np.int32).ravel(), scores[idx]), cfg
+    if cfg != "config5":
+        assert np.array_equal(ref.astype(np.int32).ravel(), scores[idx]), cfg
+        return
+    small = scores[idx] <= 32767
+    assert np.array_equal(ref.astype(np.int32).ravel()[small], scores[idx][small])
+    big = idx[~small]
+    assert 0 < len(big) <= 2 * planted and scores[big].min() > 32767
+    big = big[::3]          # the scalar oracle needs 0.25 s per 8192 x 8192 pair and thread
+    b_off = np.zeros(len(big) + 1, dtype=np.uint64)
+    b_off[1:] = np.cumsum(lens[big])
+    b_flat = np.concatenate([flat[int(off[i]):int(off[i + 1])] for i in big])
+    assert np.array_equal(orc.score_db(q, b_flat, b_off, tab, -2, -1), scores[big])
 
 
 def test_long_tail_database(swg, ctx, orc):
