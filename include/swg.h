@@ -247,6 +247,10 @@ int swg_group_set_query(swg_group *g, const int8_t *idx, size_t lq);
 int swg_group_load(swg_group *g, const int8_t *flat, const uint64_t *offsets, size_t n);
 int swg_group_search(swg_group *g, int32_t *scores_out, swg_hit *topk_out, size_t k, size_t *n_hits,
                      swg_stats *stats);
+/* swg_align_hits for a group: every hit is re-run on the GPU whose shard holds the sequence. */
+int swg_group_align_hits(swg_group *g, const swg_hit *hits, size_t n_hits, swg_alignment *out, char *ops,
+                         size_t ops_stride);
+size_t swg_group_align_ops_bound(const swg_group *g);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "swg_key_hit", "swg_topk_merge_keys",
     "swg_group_create", "swg_group_destroy", "swg_group_size", "swg_group_last_error", "swg_group_set_option",
     "swg_group_set_scoring", "swg_group_set_query", "swg_group_load", "swg_group_search",
+    "swg_group_align_hits", "swg_group_align_ops_bound",
     "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
     "swg_scoring_load_matrix", "swg_query_sanitize", "swg_seqs_read", "swg_seqs_free",
     "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar",
@@ -133,6 +134,8 @@ _sig("swg_align_ops_bound", C.c_size_t, [_vp, _vp])
 _sig("swg_hit_key", C.c_uint64, [C.c_int32, C.c_uint32])
 _sig("swg_key_hit", None, [C.c_uint64, C.POINTER(Hit)])
 _sig("swg_topk_merge_keys", C.c_size_t, [_vp, C.c_size_t, C.c_size_t, _vp])
+_sig("swg_group_align_hits", C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t])
+_sig("swg_group_align_ops_bound", C.c_size_t, [_vp])
 _sig("swg_group_create", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)])
 _sig("swg_group_destroy", None, [_vp])
 _sig("swg_group_size", C.c_int, [_vp])
@@ -484,6 +487,23 @@ class Group:
         self._chk(lib.swg_group_search(self.handle, scores.ctypes.data_as(_vp) if want_scores else None,
                                        C.cast(hits, _vp) if k else None, k, C.byref(nh), st))
         return scores, [(int(hits[i].score), int(hits[i].index)) for i in range(nh.value)], [s.as_dict() for s in st]
+
+    def align_hits(self, hits):
+        """Alignments of hits of a group search (see Context.align_hits)."""
+        n = len(hits)
+        arr = (Hit * max(n, 1))()
+        for i, (sc, ix) in enumerate(hits):
+            arr[i].score, arr[i].index = int(sc), int(ix)
+        out = (Alignment * max(n, 1))()
+        stride = int(lib.swg_group_align_ops_bound(self.handle))
+        ops = C.create_string_buffer(max(1, n * stride))
+        self._chk(lib.swg_group_align_hits(self.handle, C.cast(arr, _vp), n, C.cast(out, _vp), C.cast(ops, _vp), stride))
+        res = []
+        for i in range(n):
+            a = {f: int(getattr(out[i], f)) for f, _ in Alignment._fields_ if f != "reserved"}
+            a["ops"] = ops.raw[i * stride:i * stride + a["n_ops"]].decode()
+            res.append(a)
+        return res
 
     def close(self):
         if self.handle:

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -248,5 +250,63 @@ extern "C" int swg_group_search(swg_group *g, int32_t *scores_out, swg_hit *topk
     }
     const size_t m = swg_topk_merge_keys(keys.data(), keys.size(), k, topk_out);
     if (n_hits) *n_hits = m;
+    return SWG_OK;
+}
+
+// Alignments of hits of a group search: every hit is re-run on the GPU whose shard holds the
+// sequence (swg_align_hits, swg_trace.hip), shard after shard -- a cold path.
+extern "C" size_t swg_group_align_ops_bound(const swg_group *g)
+{
+    size_t b = 0;
+    if (g)
+        for (int i = 0; i < g->n; ++i)
+            if (g->db[i]) b = std::max(b, swg_align_ops_bound(g->ctx[i], g->db[i]));
+    return b;
+}
+
+extern "C" int swg_group_align_hits(swg_group *g, const swg_hit *hits, size_t n_hits, swg_alignment *out, char *ops,
+                                    size_t ops_stride)
+{
+    if (!g) return swg_set_global_error(SWG_ERR_ARG, "swg_group_align_hits: NULL group");
+    if (n_hits && (!hits || !out)) return gerr(g, SWG_ERR_ARG, "swg_group_align_hits: NULL argument");
+    if (ops && ops_stride == 0) return gerr(g, SWG_ERR_ARG, "swg_group_align_hits: ops_stride is 0");
+    for (int i = 0; i < g->n; ++i)
+        if (!g->db[i]) return gerr(g, SWG_ERR_STATE, "swg_group_align_hits: no database loaded");
+    // shard of every wanted sequence: bins are dealt round-robin, so ask the shards' own index lists
+    std::vector<int> shard(n_hits, -1);
+    {
+        std::unordered_map<uint32_t, int> owner;
+        owner.reserve(n_hits * 2);
+        for (size_t h = 0; h < n_hits; ++h) owner[hits[h].index] = -1;
+        for (int i = 0; i < g->n; ++i) {
+            for (const uint32_t oi : g->db[i]->order) { // ~0u marks an empty slot of the last bin
+                auto it = oi == 0xFFFFFFFFu ? owner.end() : owner.find(oi);
+                if (it != owner.end()) it->second = i;
+            }
+        }
+        for (size_t h = 0; h < n_hits; ++h) {
+            shard[h] = owner[hits[h].index];
+            if (shard[h] < 0)
+                return gerr(g, SWG_ERR_ARG, "swg_group_align_hits: sequence " + std::to_string(hits[h].index) +
+                                                " is not in the loaded database");
+        }
+    }
+    for (int i = 0; i < g->n; ++i) {
+        std::vector<size_t> mine;
+        for (size_t h = 0; h < n_hits; ++h)
+            if (shard[h] == i) mine.push_back(h);
+        if (mine.empty()) continue;
+        std::vector<swg_hit> sub(mine.size());
+        std::vector<swg_alignment> al(mine.size());
+        std::vector<char> sub_ops(ops ? mine.size() * ops_stride : 0);
+        for (size_t m = 0; m < mine.size(); ++m) sub[m] = hits[mine[m]];
+        const int rc = swg_align_hits(g->ctx[i], g->db[i], sub.data(), sub.size(), al.data(), ops ? sub_ops.data() : nullptr,
+                                      ops_stride);
+        if (rc != SWG_OK) return gerr(g, rc, swg_last_error(g->ctx[i]));
+        for (size_t m = 0; m < mine.size(); ++m) {
+            out[mine[m]] = al[m];
+            if (ops) memcpy(ops + mine[m] * ops_stride, sub_ops.data() + m * ops_stride, (size_t)al[m].n_ops + 1);
+        }
+    }
     return SWG_OK;
 }

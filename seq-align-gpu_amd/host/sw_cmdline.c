@@ -167,7 +167,7 @@ int main(int argc, char **argv)
     if (!qpath || !dbpath) usage(argv[0], "Both query and database files must be provided");
     if (!have_matrix) usage(argv[0], "--substitution_matrix is required (the fill scores from the matrix only)");
     if (packed && (print_seq || print_fasta)) usage(argv[0], "--printseq/--printfasta need the FASTA database, not --packed");
-    if ((packed || savedb || allq || align) && gpus > 0) usage(argv[0], "--packed/--savedb/--allqueries/--align work with one GPU (--gpu)");
+    if ((packed || savedb || allq) && gpus > 0) usage(argv[0], "--packed/--savedb/--allqueries work with one GPU (--gpu)");
     if (align && topk == 0) usage(argv[0], "--align reports the alignments of the --topk hits: give --topk K");
 
     char err[512];
@@ -315,13 +315,14 @@ next_query:
             printf("%d\t%u\t%s\n", hits[i].score, hits[i].index, packed ? "" : db.names + db.name_off[hits[i].index]);
     }
     if (align && n_hits > 0) {
-        const size_t stride = swg_align_ops_bound(ctx, pdb);
+        const size_t stride = grp ? swg_group_align_ops_bound(grp) : swg_align_ops_bound(ctx, pdb);
         swg_alignment *al = (swg_alignment *)calloc(n_hits, sizeof *al);
         char *ops = (char *)malloc(n_hits * stride);
         char *line = (char *)malloc(stride);
         if (!al || !ops || !line) return EXIT_FAILURE;
-        if (swg_align_hits(ctx, pdb, hits, n_hits, al, ops, stride) != SWG_OK) {
-            fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
+        if ((grp ? swg_group_align_hits(grp, hits, n_hits, al, ops, stride)
+                 : swg_align_hits(ctx, pdb, hits, n_hits, al, ops, stride)) != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", grp ? swg_group_last_error(grp) : swg_last_error(ctx));
             return EXIT_FAILURE;
         }
         for (size_t i = 0; i < n_hits; i++) {

@@ -155,8 +155,9 @@ def test_cli_config1_against_oracle(swg, orc, tmp_path):
         assert "Total Entries: %d" % len(seqs) in text
 
     # the multi-GPU route of the tool (one device here): same stream of entries
-    r1 = _run("--substitution_matrix", B62, "--gpus", "1", "--topk", "3", "--files", str(qf), str(df))
+    r1 = _run("--substitution_matrix", B62, "--gpus", "1", "--topk", "3", "--align", "--files", str(qf), str(df))
     assert r1.returncode == 0, r1.stderr
+    assert sum(1 for l in r1.stdout.splitlines() if l.startswith("Alignment #")) == 3
     assert {int(m.group(1)): int(m.group(2)) for m in ENTRY_RX.finditer(r1.stdout)} == dict(enumerate(want))
 
     # an illegal residue: the reference's message and exit status 1

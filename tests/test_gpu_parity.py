@@ -616,6 +616,13 @@ def test_group_with_rccl_merge(swg, orc):
         none, hits2, _ = grp.search(want_scores=False, k=7)
         assert none is None and hits2 == orc.topk(want, 7)
         assert len(stats) == 1 and stats[0]["cells"] == len(q) * len(flat)
+        als = grp.align_hits(hits[:6])
+        for a, (s_, i_) in zip(als, hits[:6]):
+            sc_, co, ops = orc.pair_trace(q, flat[int(off[i_]):int(off[i_ + 1])], sc.table(), -2, -1)
+            assert (a["score"], a["index"], a["ops"]) == (s_, i_, ops) and sc_ == s_
+            assert (a["q_begin"], a["q_end"], a["d_begin"], a["d_end"]) == co
+        with pytest.raises(swg.SwgError):
+            grp.align_hits([(0, len(off) - 1)])
         grp.close()
 
 
