@@ -266,3 +266,15 @@ def test_hit_keys_and_merge(swg, orc):
     parts = [swg.topk_merge_keys(keys[r::4], 100) for r in range(4)]
     shard_keys = np.array([swg.hit_key(s, i) for p in parts for (s, i) in p] + [0, 0], dtype=np.uint64)
     assert swg.topk_merge_keys(shard_keys, 100) == orc.topk(scores, 100)
+
+
+def test_host_threads_respect_the_process_share(swg):
+    """swg_host_threads: never more than the CPUs this process may run on, and OMP_NUM_THREADS wins."""
+    import subprocess, sys
+    n = swg.lib.swg_host_threads()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    code = ("import sys; sys.path.insert(0, %r); import swg_loader; "
+            "print(swg_loader.load().lib.swg_host_threads())" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"),
+                       stdout=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "1"
