@@ -5,8 +5,9 @@
 // best pairs; this unit re-runs exactly those K pairs with the recurrence of src/alignment.c:124-161
 // kept whole and walks back from the best match cell.  It is a cold path (K pairs, not the
 // database): one workgroup per pair sweeps the anti-diagonals of the pair's matrix, 256 cells at a
-// time, in int32, three rotating diagonals per state in HBM/L2, one predecessor byte per cell
-// stored diagonal-major (coalesced), then one lane follows the bytes back.  Everything runs on
+// time, in int32, three rotating diagonals per state (in LDS for queries up to 1700 columns, else
+// in HBM/L2), one predecessor byte per cell stored diagonal-major (coalesced), then one lane follows
+// the bytes back.  Everything runs on
 // the GPU; like the rest of the library there is no CPU path.
 #include "swg_host_internal.h"
 
@@ -42,6 +43,7 @@ struct SwgTraceParams {
 };
 
 #define SWG_TRACE_THREADS 256
+#define SWG_TRACE_LDS_COLS 1700 /* 9 * (cols + 1) * 4 bytes <= 60 KB */
 
 // predecessor code of one state: 0 = the alignment starts here, 1/2/3 = came from H/A/B
 __device__ __forceinline__ uint32_t trace_pick(int32_t m, int32_t x, int32_t y)
@@ -49,8 +51,12 @@ __device__ __forceinline__ uint32_t trace_pick(int32_t m, int32_t x, int32_t y)
     return m == 0 ? 0u : x == m ? 1u : y == m ? 2u : 3u;
 }
 
+// IN_LDS: the nine rotating anti-diagonals live in the workgroup's LDS (queries up to
+// SWG_TRACE_LDS_COLS columns; one dependent sweep then waits for LDS, not for L2).
+template <bool IN_LDS>
 __global__ __launch_bounds__(SWG_TRACE_THREADS) void swg_trace_kernel(SwgTraceParams p)
 {
+    extern __shared__ int32_t s_diag[];
     __shared__ int8_t s_sub[1024];
     __shared__ int s_best;
     __shared__ unsigned long long s_pos;
@@ -63,7 +69,9 @@ __global__ __launch_bounds__(SWG_TRACE_THREADS) void swg_trace_kernel(SwgTracePa
         s_pos = ~0ull;
         s_n = 0;
     }
-    int32_t *X = p.diag + (size_t)blockIdx.x * 9 * w;
+    int32_t *X;
+    if (IN_LDS) X = s_diag;
+    else X = p.diag + (size_t)blockIdx.x * 9 * w;
     const int8_t *d = p.res + job.res_off;
     uint8_t *dir = p.dir + job.dir_off;
     const int go = p.go, ge = p.ge;
@@ -212,6 +220,7 @@ extern "C" int swg_align_hits(swg_ctx *ctx, const swg_db *db, const swg_hit *hit
     std::vector<SwgTraceOut> h_out(n_hits);
     std::vector<char> h_ops;
     size_t max_chunk = 0, max_dir = 0;
+    const bool in_lds = lq <= SWG_TRACE_LDS_COLS;
     {
         // chunks of consecutive hits whose predecessor bytes fit 2 GiB together (a single larger pair goes alone)
         const uint64_t budget = 2ull << 30;
@@ -232,7 +241,7 @@ extern "C" int swg_align_hits(swg_ctx *ctx, const swg_db *db, const swg_hit *hit
     TRACE_TRY(ctx, hipMalloc(&d_sub, 1024));
     TRACE_TRY(ctx, hipMalloc(&d_res, std::max<size_t>(res.size(), 4)));
     TRACE_TRY(ctx, hipMalloc(&d_jobs, n_hits * sizeof(SwgTraceJob)));
-    TRACE_TRY(ctx, hipMalloc(&d_diag, max_chunk * 9 * (lq + 1) * sizeof(int32_t)));
+    TRACE_TRY(ctx, hipMalloc(&d_diag, in_lds ? 16 : max_chunk * 9 * (lq + 1) * sizeof(int32_t)));
     TRACE_TRY(ctx, hipMalloc(&d_dir, std::max<size_t>(max_dir, 4)));
     TRACE_TRY(ctx, hipMalloc(&d_ops, max_chunk * dev_stride));
     TRACE_TRY(ctx, hipMalloc(&d_out, n_hits * sizeof(SwgTraceOut)));
@@ -257,7 +266,11 @@ extern "C" int swg_align_hits(swg_ctx *ctx, const swg_db *db, const swg_hit *hit
         p.query = d_query, p.sub = d_sub, p.res = d_res, p.jobs = d_jobs + b, p.diag = d_diag, p.dir = d_dir;
         p.ops = d_ops, p.out = d_out + b, p.lq = (uint32_t)lq, p.ops_stride = (uint32_t)dev_stride;
         p.go = ctx->gap_open + ctx->gap_extend, p.ge = ctx->gap_extend; // src/alignment.c:58-59
-        hipLaunchKernelGGL(swg_trace_kernel, dim3((unsigned)nb), dim3(SWG_TRACE_THREADS), 0, ctx->stream, p);
+        if (in_lds)
+            hipLaunchKernelGGL(swg_trace_kernel<true>, dim3((unsigned)nb), dim3(SWG_TRACE_THREADS),
+                               9 * (lq + 1) * sizeof(int32_t), ctx->stream, p);
+        else
+            hipLaunchKernelGGL(swg_trace_kernel<false>, dim3((unsigned)nb), dim3(SWG_TRACE_THREADS), 0, ctx->stream, p);
         TRACE_TRY(ctx, hipGetLastError());
         TRACE_TRY(ctx, hipMemcpyAsync(h_out.data() + b, d_out + b, nb * sizeof(SwgTraceOut), hipMemcpyDeviceToHost,
                                       ctx->stream));
