@@ -6,8 +6,28 @@
 
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
+
+// Allocator whose resize() leaves new elements uninitialised: the big residue arrays are filled
+// by parallel loops, and pages should be first touched by the threads that fill them instead of by
+// one thread writing zeros (a 10M-sequence database is 8 GB of them).
+template <class T> struct SwgNoInit {
+    using value_type = T;
+    SwgNoInit() = default;
+    template <class U> SwgNoInit(const SwgNoInit<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { ::operator delete(p); }
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a)
+    {
+        ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const SwgNoInit<U> &) const { return true; }
+    template <class U> bool operator!=(const SwgNoInit<U> &) const { return false; }
+};
 
 // Stream layout of the diagonal engine: pairs of adjacent sorted ranks, dealt to
 // n_streams lane groups longest first; tokens are stored stream-major.
@@ -86,8 +106,8 @@ struct swg_db {
     std::vector<uint32_t> bin_nblk; // [n_bins]
     std::vector<uint32_t> order;    // [n_bins*128] original index of each slot, ~0u = empty
     std::vector<uint32_t> lens;     // [n_bins*128]
-    std::vector<uint32_t> packed;   // residue dwords (bins, systolic engine)
-    std::vector<uint8_t> codes;     // residue bytes (index<<3) by sorted rank, back to back
+    std::vector<uint32_t, SwgNoInit<uint32_t>> packed; // residue dwords (bins, systolic engine)
+    std::vector<uint8_t, SwgNoInit<uint8_t>> codes;    // residue bytes (index<<3) by sorted rank, back to back
     std::vector<uint64_t> code_off; // [n_bins*128+1]
     SwgPairTokens ptok;             // pair-major tokens (work-queue form of the diagonal engine)
     SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs

@@ -101,7 +101,7 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
     db->rows_padded = rows_padded;
     db->max_nblk = nb ? *std::max_element(db->bin_nblk.begin(), db->bin_nblk.end()) : 0;
     try {
-        db->packed.assign(dwords, 0u);
+        db->packed.resize(dwords); // every bin zeroes its own blocks in the parallel loop below
     } catch (const std::bad_alloc &) {
         delete db;
         return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory (%llu dwords)",
@@ -111,7 +111,7 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
     try {
         db->code_off.assign(nb * SWG_BIN + 1, 0);
         for (size_t i = 0; i < nb * SWG_BIN; ++i) db->code_off[i + 1] = db->code_off[i] + db->lens[i];
-        db->codes.assign(residues, 0);
+        db->codes.resize(residues); // written completely, sequence by sequence, below
     } catch (const std::bad_alloc &) {
         delete db;
         return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
@@ -121,6 +121,7 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
 #pragma omp parallel for schedule(dynamic, 4) num_threads(swg_host_threads())
     for (long long lb = 0; lb < (long long)nb; ++lb) {
         uint32_t *base = pk + db->bin_off[lb];
+        memset(base, 0, (size_t)db->bin_nblk[lb] * SWG_BIN * sizeof(uint32_t)); // padding rows and empty slots
         for (size_t s = 0; s < SWG_BIN; ++s) {
             const uint32_t oi = db->order[lb * SWG_BIN + s];
             if (oi == 0xFFFFFFFFu) continue;
@@ -151,14 +152,14 @@ struct FileHeader {
     uint64_t n_total, n_local, n_bins, max_nblk, residues, rows_padded;
     uint64_t n_packed, n_codes;
 };
-template <class T> bool put(FILE *f, const std::vector<T> &v)
+template <class V> bool put(FILE *f, const V &v)
 {
-    return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size();
+    return v.empty() || fwrite(v.data(), sizeof(typename V::value_type), v.size(), f) == v.size();
 }
-template <class T> bool get(FILE *f, std::vector<T> &v, size_t n)
+template <class V> bool get(FILE *f, V &v, size_t n)
 {
     v.resize(n);
-    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+    return n == 0 || fread(v.data(), sizeof(typename V::value_type), n, f) == n;
 }
 } // namespace
 
