@@ -302,6 +302,8 @@ class Database:
     packed_bytes = property(lambda self: lib.swg_db_packed_bytes(self.handle))
 
     def order(self):
+        if self.count == 0:                 # a shard may hold nothing (fewer bins than shards)
+            return np.zeros(0, dtype=np.uint32)
         return np.ctypeslib.as_array(lib.swg_db_order(self.handle), shape=(self.count,)).copy()
 
     def save(self, path):

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the multi-GPU path of bench.py without GPUs.  Each rank packs
+"""CPU, world sizes 2 and 4 over gloo: the multi-GPU path of bench.py without GPUs.  Each rank packs
 its shard of one database (round-robin bins), scores it with the oracle (standing in for the
 GPU), and the ranks merge their top-K lists with the same single max-all-reduce bench.py uses."""
 import os
@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, n_seqs):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -22,17 +22,20 @@ def _worker(rank, world, port, tmp):
     try:
         sc = swg.load_scoring("BLOSUM62")
         q = swg.synth_query(11, 64)
-        flat, off = swg.synth_db(11, 700, max_len=200)
+        flat, off = swg.synth_db(11, n_seqs, max_len=200)
         want = orc.score_db(q, flat, off, sc.table(), -2, -1)
         shard = swg.Database(flat, off, rank, world)
         mine = shard.order()
+        mine = mine[mine != 0xFFFFFFFF]                            # empty slots of the last bin
+        assert len(mine) == shard.count
         local = sorted(((-int(want[i]), int(i)) for i in mine))[:50]
         hits = [(-s, i) for s, i in local]                         # what swg_search would return
         merged = bench.TopKMerger(swg, 50, rank, world, "cpu").merge(hits)
         assert merged == orc.topk(want, 50), rank
         # the shards partition the database
         import torch
-        seen = torch.zeros(700, dtype=torch.int64)
+        seen = torch.zeros(n_seqs, dtype=torch.int64)
+        mine = mine[mine != 0xFFFFFFFF]
         seen[torch.from_numpy(mine.astype(np.int64))] = 1
         dist.all_reduce(seen)
         assert int(seen.min()) == 1 and int(seen.max()) == 1
@@ -41,8 +44,11 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_topk_merge(tmp_path):
+@pytest.mark.parametrize("world,n_seqs", [(2, 700), (4, 1100), (4, 300)])
+def test_shards_and_topk_merge_over_gloo(tmp_path, world, n_seqs):
+    """(2, 700): three bins per rank; (4, 1100): uneven shards (3, 2, 2, 2 bins, the last one partly
+    empty); (4, 300): three bins for four ranks -- one rank holds nothing and contributes no hit."""
     import torch.multiprocessing as mp
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    port = 29500 + (os.getpid() * 7 + world * 31 + n_seqs) % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n_seqs), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
