@@ -213,6 +213,10 @@ int main(int argc, char **argv)
     phase("letters to table indices");
     int32_t *scores = (int32_t *)calloc(db.n ? db.n : 1, sizeof(int32_t));
     swg_hit *hits = (swg_hit *)calloc(topk ? (size_t)topk : 1, sizeof(swg_hit));
+    if (!scores || !hits) {
+        fprintf(stderr, "Error: out of memory\n");
+        return EXIT_FAILURE;
+    }
     size_t n_hits = 0;
     double total_ms = 0.0;
     swg_ctx *ctx = NULL;
@@ -220,6 +224,7 @@ int main(int argc, char **argv)
     if (gpus > 0) {
         /* database sharded over several GPUs of this process */
         swg_stats *st = (swg_stats *)calloc((size_t)gpus, sizeof(swg_stats));
+        if (!st) return EXIT_FAILURE;
         int rc = swg_group_create(NULL, (int)gpus, 0, &grp);
         if (rc != SWG_OK) {
             fprintf(stderr, "Error: %s\n", swg_global_error());
