@@ -278,3 +278,18 @@ def test_host_threads_respect_the_process_share(swg):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"),
                        stdout=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "1"
+
+
+def test_packed_image_is_deterministic(swg, tmp_path):
+    """The residue arrays are allocated uninitialised and filled by parallel loops: two packs of the
+    same input (and a pack on one thread's worth of bins) must give byte-identical files, i.e. no
+    byte of the image is left to chance."""
+    flat, off = swg.synth_db(99, 1000, max_len=900)
+    a, b = tmp_path / "a.swg", tmp_path / "b.swg"
+    junk = np.full(8 << 20, 0x5A, dtype=np.uint8)      # dirty the heap between the two packs
+    swg.Database(flat, off).save(str(a))
+    del junk
+    swg.Database(flat, off).save(str(b))
+    assert a.read_bytes() == b.read_bytes()
+    db = swg.Database(path=str(a))
+    assert db.count == 1000 and db.residues == len(flat)
