@@ -1,0 +1,77 @@
+"""Static instruction mix of one database row of the work-queue fill kernel, from the built library.
+
+    python tools/row_isa.py [K] > profiles/rNN_kK_row_isa.txt
+
+Extracts the gfx950 code object from seq-align-gpu_amd/libswg.so (llvm-objdump --offloading),
+disassembles swg_diag_dyn_kernel<K,16,false,false> and classifies the instructions of the first
+unrolled row (from the end of the queue-event branch to the next one) -- what competes with the
+recurrence for the VALU port and what issues beside it."""
+import collections, glob, os, re, shutil, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 23
+tmp = tempfile.mkdtemp()
+lib = os.path.join(tmp, "libswg.so")
+shutil.copy(os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so"), lib)
+subprocess.run([OBJDUMP, "--offloading", lib], stdout=subprocess.DEVNULL, check=True, cwd=tmp)
+text = ""
+for co in sorted(glob.glob(lib + ".*gfx950")):
+    text += subprocess.run([OBJDUMP, "-d", co], stdout=subprocess.PIPE, text=True).stdout
+lines = text.split("\n")
+name = "_Z19swg_diag_dyn_kernelILi%dELi16ELb0ELb0E" % K
+start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <%s" % name, l))
+end = start + 1
+while end < len(lines) and not re.match(r"^[0-9a-f]+ <_Z", lines[end]):
+    end += 1
+body = lines[start:end]
+
+
+def parse(l):
+    m = re.match(r"^\s+(\S+)\s+(.*?)\s*//", l)
+    return (m.group(1), m.group(2)) if m else None
+
+
+def kind(op):
+    if op.startswith("v_pk_") or op.startswith("v_perm"):
+        return "VALU recurrence (v_pk_*, v_perm_b32)"
+    if "dpp" in op:
+        return "VALU DPP move (token / edge hand-over)"
+    if op.startswith("v_"):
+        return "VALU other (addresses, flags, selects)"
+    if op.startswith("ds_"):
+        return "LDS"
+    if op.startswith("s_waitcnt"):
+        return "s_waitcnt"
+    if op.startswith("s_nop"):
+        return "s_nop"
+    if op.startswith("s_cbranch") or op.startswith("s_branch"):
+        return "branch"
+    if op.startswith("s_"):
+        return "SALU"
+    return "memory / other"
+
+
+# rows are unrolled four times; a row begins where the profile address of its token is formed:
+# the first v_and_b32 with 0xf8 after a backward branch, and ends before the next one
+starts = [i for i, l in enumerate(body) if (parse(l) or ("", ""))[0] == "v_and_b32_e32" and "0xf8" in l
+          and not any("0xf8" in body[j] for j in range(max(0, i - 3), i))]
+a, b = starts[0], starts[1]
+mix = collections.Counter()
+others = []
+for l in body[a:b]:
+    p = parse(l)
+    if not p:
+        continue
+    k = kind(p[0] if "dpp" not in p[1] else p[0] + "_dpp")
+    mix[k] += 1
+    if not k.startswith("VALU recurrence"):
+        others.append("    %-22s %s" % (p[0], p[1][:80]))
+print("kernel %s..., %d instructions in all; one unrolled row = %d static instructions" % (name, len(body), b - a))
+print("(both lane-group hand-over forms -- row_shr for 16/32 lanes, wave_shr for 64 -- and the skipped")
+print(" score-store / queue-event blocks are in the listing: a row executes only one form)")
+for k, v in sorted(mix.items(), key=lambda kv: -kv[1]):
+    print("  %4d  %s" % (v, k))
+print("everything that is not the recurrence, in program order:")
+print("\n".join(others))
+shutil.rmtree(tmp)
