@@ -4,14 +4,28 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path (swg_search: int16 fill, saturation re-score when
-possible, top-K) over one resident synthetic database; for N > 1 every rank owns an
-independent shard of the same shape (weak scaling, no data-path collective) and the only
-exchange is one RCCL max-all-reduce of the n*K top-K keys per step.
+A step = one pass of the hot path (swg_search: int16 fill, saturation re-score when possible,
+top-K) over one resident synthetic database of the shapes of SURVEY 8d.
 
-The JSON line carries BASELINE.json's metric (GCUPS = lq * sum(len) / t / 1e9 over real
-residues), the HBM roofline of the fill kernel, and the reference's own AVX2+OpenMP fill
-timed on this host (oracle/_ref, built from the reference's sources) as `cpu_baseline`.
+One GPU, no --config: the JSON line's headline (`value`, `config`, `roofline`, `cpu_baseline`) is
+config 3, the largest single-GPU configuration of BASELINE.json (500 aa vs 570 000 sequences); the
+`configs` object holds one block of the same shape for each of configs 2, 3, 4 (one GPU's eighth of
+the 10M-sequence database) and 5, and `scaling_reference` is config 4's WHOLE 10M-sequence database
+searched on this one GPU -- the N = 1 point of the curve below.
+
+N > 1 (one rank per GPU, torch.distributed over RCCL; SWG_BENCH_FORCE_DIST=1 rehearses the path with
+one rank): config 4 as ONE 10M-sequence database.  Every rank derives the same global length order,
+generates only the residues of its own bins (round-robin by bin: swg_synth_db_shard), packs them
+(swg_db_pack_shard) and searches them with no data-path collective; the only exchange is one RCCL
+max-all-reduce of the n*K top-K keys per step.  Total work is fixed as N grows: `scaling: "strong"`,
+value = cells of the whole database * steps / max-over-ranks time.  Once, outside the timed region,
+the merged top-K is checked: every candidate's score against the int32 oracle, a seeded sample of
+each shard against the K-th key, and the all-reduce merge against a plain gather-and-sort.
+
+The JSON line carries BASELINE.json's metric (GCUPS = lq * sum(len) / t / 1e9 over real residues),
+the HBM roofline of the fill kernel beside the roof that binds it (VALU issue), and the reference's
+own AVX2+OpenMP fill timed on this host (oracle/_ref, built from the reference's sources) as
+`cpu_baseline`.  The oracle is used as the checker only, never inside a timed region.
 """
 import argparse
 import json
@@ -41,18 +55,23 @@ CONFIGS = {
     1: dict(lq=128, n=1024, matrix="BLOSUM62"),
     2: dict(lq=367, n=100000, matrix="PAM250"),
     3: dict(lq=500, n=570000, matrix="BLOSUM62"),
-    4: dict(lq=3000, n=1250000, matrix="BLOSUM62"),   # one GPU's eighth of the 10M-sequence DB
+    4: dict(lq=3000, n=1250000, matrix="BLOSUM62", n_full=10000000),   # n: one GPU's eighth of the 10M-sequence DB
     5: dict(lq=8192, n=100000, matrix="BLOSUM62", similar=0.01),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak
+HEADLINE = 3            # largest single-GPU configuration of BASELINE.json
+SHARDED = 4             # the configuration N > 1 runs, as one database dealt by bins
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak
+METRIC = "GCUPS (DP cell updates/s) at 1/2/4/8 MI355X; bit-exact max scores vs CPU ref"
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--config", type=int, default=0,
+                    help="0 (default): one GPU = configs 3 (headline), 2, 4-share, 5 and the 10M scaling reference; "
+                         "N GPUs = config 4 as one sharded database.  C: that configuration alone")
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--max-waves", type=int, default=0)
@@ -70,6 +89,7 @@ def main():
     ap.add_argument("--long-group", type=int, default=0, help="experiment: lanes per pair of the long class")
     ap.add_argument("--lq", type=int, default=0, help="experiment: override the query length of the config")
     ap.add_argument("--nseq", type=int, default=0, help="experiment: override the sequence count of the config")
+    ap.add_argument("--force-bits", type=int, default=0, help="experiment: 32 = the exact int32 path for everything")
     ap.add_argument("--autotune", action="store_true",
                     help="time the best-ranked geometries on the device at the first search (default: the cost model alone, "
                          "so that every rank of a multi-GPU run uses the same plan)")
@@ -78,147 +98,195 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true",
                     help="skip the one-off search from host buffers (PCIe-inclusive figure, reported beside value)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the top-K check against the oracle (outside the timed region)")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="one GPU: skip the whole 10M-sequence config-4 database (the N = 1 point of the scaling curve)")
+    ap.add_argument("--only-headline", action="store_true", help="one GPU: the headline configuration alone")
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # SWG_BENCH_FORCE_DIST=1: take the collective path even with one rank (rehearsal on a 1-GPU box)
-    use_dist = world > 1 or os.environ.get("SWG_BENCH_FORCE_DIST") == "1"
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
 
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+class Env:
+    """rank / world, torch.distributed (only when the collective path is taken) and the library."""
 
-    lib_path = os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so")
-    if not os.path.exists(lib_path):
-        if rank == 0:
-            swg_loader.build_module().build()
-        if use_dist:
-            dist.barrier()
-    swg = swg_loader.load()
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # SWG_BENCH_FORCE_DIST=1: take the collective path even with one rank (rehearsal on a 1-GPU box)
+        self.use_dist = self.world > 1 or os.environ.get("SWG_BENCH_FORCE_DIST") == "1"
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+            args.gpus = self.world
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        torch.cuda.set_device(self.local_rank)
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+        lib_path = os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so")
+        if not os.path.exists(lib_path):
+            if self.rank == 0:
+                swg_loader.build_module().build()
+            if self.use_dist:
+                dist.barrier()
+        self.swg = swg_loader.load()
 
-    cfg = dict(CONFIGS[args.config])
-    if args.lq:
-        cfg["lq"] = args.lq
-    if args.nseq:
-        cfg["n"] = args.nseq
-    lq, n = cfg["lq"], cfg["n"]
-    sc = swg.load_scoring(cfg["matrix"])
-    seed = 0x5EED0000 + args.config
-    q = swg.synth_query(seed, lq)
-    shard_seed = seed + 0x10000 * rank          # every rank: an independent shard of the same shape
-    if cfg.get("similar"):
-        flat, off, _ = swg.synth_db(shard_seed, n, query=q, fraction=cfg["similar"], subst=0.05)
-    elif args.uniform_len:
-        flat, off = swg.synth_db(shard_seed, n, min_len=args.uniform_len, max_len=args.uniform_len)
-    else:
-        flat, off = swg.synth_db(shard_seed, n)
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    ctx = swg.Context(local_rank)
+    def close(self):
+        if self.use_dist:
+            self.dist.destroy_process_group()
+
+
+def make_context(env, q, sc):
+    a = env.args
+    ctx = env.swg.Context(env.local_rank)
     ctx.set_scoring(sc, -2, -1)
     ctx.set_query(q)
-    ctx.set_option("cols_per_wave", args.cols)
-    ctx.set_option("max_waves", args.max_waves)
-    ctx.set_option("workgroups", args.workgroups)
-    ctx.set_option("engine", args.engine)
-    ctx.set_option("group_lanes", args.group)
-    ctx.set_option("long_split", args.long_split)
-    ctx.set_option("long_cols", args.long_cols)
-    ctx.set_option("long_group", args.long_group)
-    ctx.set_option("autotune", 1 if args.autotune and not args.no_autotune else 0)
-    ctx.set_option("work_queue", 0 if args.static_streams else 1)
-    if args.side_readout >= 0:
-        ctx.set_option("side_readout", args.side_readout)
-    if args.long_helps:
+    ctx.set_option("cols_per_wave", a.cols)
+    ctx.set_option("max_waves", a.max_waves)
+    ctx.set_option("workgroups", a.workgroups)
+    ctx.set_option("engine", a.engine)
+    ctx.set_option("group_lanes", a.group)
+    ctx.set_option("long_split", a.long_split)
+    ctx.set_option("long_cols", a.long_cols)
+    ctx.set_option("long_group", a.long_group)
+    ctx.set_option("force_bits", a.force_bits)
+    ctx.set_option("autotune", 1 if a.autotune and not a.no_autotune else 0)
+    ctx.set_option("work_queue", 0 if a.static_streams else 1)
+    if a.side_readout >= 0:
+        ctx.set_option("side_readout", a.side_readout)
+    if a.long_helps:
         ctx.set_option("long_helps", 1)
-    if args.prio_share >= 0:
-        ctx.set_option("prio_share", args.prio_share)
-    db = swg.Database(flat, off).upload(ctx)
+    if a.prio_share >= 0:
+        ctx.set_option("prio_share", a.prio_share)
+    return ctx
+
+
+def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclusive_leg=False, cpu_leg=False):
+    """One configuration: generate, pack, upload, warm up, time exactly `steps` steps between fences.
+    sharded: the database is ONE global database dealt by bins over the ranks (strong scaling), else an
+    independent database on this rank.  Returns the block dict (rank 0) or None."""
+    a, swg = env.args, env.swg
+    cfg = dict(CONFIGS[cnum])
+    if a.lq:
+        cfg["lq"] = a.lq
+    if a.nseq:
+        cfg["n"] = a.nseq
+    lq = cfg["lq"]
+    n = n_override or cfg["n"]
+    K = a.topk
+    sc = swg.load_scoring(cfg["matrix"])
+    seed = 0x5EED0000 + cnum
+    q = swg.synth_query(seed, lq)
+    t_gen0 = time.perf_counter()
+    if sharded:
+        sh = swg.synth_db_shard(seed, n, env.rank, env.world, query=q if cfg.get("similar") else None,
+                                fraction=cfg.get("similar", 0.0), subst=0.05)
+        flat, off, index = sh["flat"], sh["offsets"], sh["index"]
+        residues_total = sh["residues_total"]
+    else:
+        if cfg.get("similar"):
+            flat, off, _ = swg.synth_db(seed, n, query=q, fraction=cfg["similar"], subst=0.05)
+        elif a.uniform_len:
+            flat, off = swg.synth_db(seed, n, min_len=a.uniform_len, max_len=a.uniform_len)
+        else:
+            flat, off = swg.synth_db(seed, n)
+        index = None
+        residues_total = int(off[-1])
+    t_gen = time.perf_counter() - t_gen0
+
+    ctx = make_context(env, q, sc)
+    t0 = time.perf_counter()
+    hdb = swg.Database(flat, off, index=index, n_total=n) if sharded else swg.Database(flat, off)
+    t_pack = time.perf_counter() - t0
+    db = hdb.upload(ctx)
     residues = int(db.residues)
     # setup, untimed like the upload: the first search of a query length plans the kernel geometry
     # for this database (and with --autotune times the best-ranked plans on this device)
-    ctx.search(db, want_scores=False, k=args.topk)
+    ctx.search(db, want_scores=False, k=K)
 
-    K = args.topk
-    merger = TopKMerger(swg, K, rank, world, "cuda") if use_dist else None
-
+    merger = TopKMerger(swg, K, env.rank, env.world, "cuda") if env.use_dist else None
     # Steps are software-pipelined two deep: search i+1 is queued on the GPU before the host finishes
     # search i (top-K read-out, and for N > 1 the all-reduce merge).  The library runs a search's
     # top-K kernels and read-out on a stream of their own, beside the start of the next fill; deeper
     # queues measured slower.  Every step still does all of its work inside the timed region.
-    depth = 1 if args.no_pipeline else args.depth
+    depth = 1 if a.no_pipeline else a.depth
 
     def finish(ticket):
-        if use_dist:
+        if env.use_dist:
             keys, st = ctx.search_end_keys(ticket)
             return merger.merge_keys(keys), st
         _, hits, st = ctx.search_end(ticket)
         return hits, st
 
-    def run_steps(n, record):
+    def run_steps(count, record):
         pending = []
-        for _ in range(n):
+        for _ in range(count):
             pending.append(ctx.search_begin(db, K))
             if len(pending) >= depth:
                 record(*finish(pending.pop(0)))
         while pending:
             record(*finish(pending.pop(0)))
 
-    run_steps(args.warmup, lambda hits, st: None)
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fill_ms, total_ms, lasts = [], [], []
+    run_steps(warmup, lambda hits, st: None)
+    fill_ms, total_ms, lasts, last_hits = [], [], [], []
 
     def record(hits, st):
         fill_ms.append(st["fill_ms"])
         total_ms.append(st["total_ms"])
         lasts.append(st)
+        last_hits[:] = [hits]
 
-    fence()
+    env.fence()
     t0 = time.perf_counter()
-    run_steps(args.steps, record)
-    fence()
+    run_steps(steps, record)
+    env.fence()
     elapsed = time.perf_counter() - t0
     last = lasts[-1]
 
-    cells_local = lq * residues
-    if use_dist:
+    torch, dist = env.torch, env.dist
+    if env.use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([cells_local], dtype=torch.float64, device="cuda")
+    if sharded:
+        cells_total = float(lq) * float(residues_total)          # ONE database, whatever the number of ranks
+    elif env.use_dist:
+        c = torch.tensor([float(lq) * residues], dtype=torch.float64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         cells_total = float(c.item())
     else:
-        cells_total = float(cells_local)
+        cells_total = float(lq) * residues
+    cells_local = float(lq) * residues
 
-    if rank == 0:
-        gcups = cells_total * args.steps / elapsed / 1e9
+    verify = None
+    if not a.no_verify:
+        verify = verify_topk(env, ctx, db, q, sc, flat, off, index, K, merger, last_hits[0])
+
+    block = None
+    if env.rank == 0:
+        gcups = cells_total * steps / elapsed / 1e9
         k_ms = float(np.mean(fill_ms))
         bytes_alg = int(last["bytes_alg"])
         achieved = bytes_alg / (k_ms * 1e-3) / 1e9
         traffic = None
-        if os.path.exists(args.traffic_json):
+        if os.path.exists(a.traffic_json):
             try:
-                tj = json.load(open(args.traffic_json))
-                traffic = tj.get("config%d" % args.config, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(a.traffic_json))
+                traffic = tj.get("config%d" % cnum, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # The binding roof is integer VALU issue, reported beside the (by construction tiny) HBM
@@ -231,16 +299,27 @@ def main():
         kernel_gcups = cells_local / (k_ms * 1e-3) / 1e9
         peak_issue = simds * 64 / 4.0 * 2.4e9 / ops_per_cell / 1e9
         peak_microbench = simds * 64 / 4.56 * 2.35e9 / ops_per_cell / 1e9
-        out = {
-            "metric": "GCUPS (DP cell updates/s) at 1/2/4/8 MI355X; bit-exact max scores vs CPU ref",
-            "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16" if last["path_bits"] == 16 else "int32", "data": "synthetic",
+        if last["engine"] == 2 and last["path_bits"] == 16:
+            kname = ("swg_diag_dyn_kernel<%d>" if last["work_queue"] else "swg_diag_kernel<%d>") % last["cols_per_wave"]
+        elif last["engine"] == 2:
+            kname = "swg_diag32_kernel"
+        else:
+            kname = "swg_fill_kernel<CellsI%d>" % last["path_bits"]
+        if sharded:
+            workload = ("config %d: 1 query (%d aa) vs ONE %d-seq synthetic protein DB dealt by bins over %d GPU(s), "
+                        "%s, gaps -2/-1, global top-%d by one RCCL all-reduce" % (cnum, lq, n, env.world, cfg["matrix"], K))
+        else:
+            workload = ("config %d: 1 query (%d aa) vs %d-seq synthetic protein DB%s, %s, gaps -2/-1, top-%d"
+                        % (cnum, lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], K))
+            if cnum == 4 and not n_override:
+                workload += " (one GPU's eighth of the 10M-sequence database)"
+        block = {
+            "value": round(gcups, 3), "unit": "GCUPS", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "dtype": "int16" if last["path_bits"] == 16 else "int32",
             "config": {
-                "workload": "config %d: 1 query (%d aa) vs %d-seq synthetic protein DB per GPU, %s, gaps -2/-1, top-%d"
-                            % (args.config, lq, n, cfg["matrix"], K),
-                "lq": lq, "n_seqs_per_gpu": n, "residues_per_gpu": residues, "matrix": cfg["matrix"],
+                "workload": workload, "lq": lq, "n_seqs": n, "n_seqs_this_gpu": int(db.count),
+                "residues_total": int(residues_total), "residues_this_gpu": residues, "matrix": cfg["matrix"],
                 "cols_per_wave": last["cols_per_wave"], "waves": last["waves"], "passes": last["passes"],
                 "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
                 "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
@@ -252,10 +331,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": (("swg_diag_dyn_kernel<%d>" if last["work_queue"] else "swg_diag_kernel<%d>") % last["cols_per_wave"])
-                if last["engine"] == 2
-                else "swg_fill_kernel<CellsI%d>" % last["path_bits"], "kernel_ms": round(k_ms, 4),
-                "bytes_alg_per_launch": bytes_alg,
+                "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
                 "binding_roof": {"bound": "valu_issue", "kernel_gcups": round(kernel_gcups, 2),
                                  "instr_per_cell": ops_per_cell,
                                  "cycles_per_wave_instr": 4.0, "clock_ghz": 2.4,
@@ -265,29 +341,96 @@ def main():
             },
             "kernel_ms": {"fill": round(k_ms, 4), "search_total": round(float(np.mean(total_ms)), 4),
                           "rescore": round(float(last["rescore_ms"]), 4), "topk_host": round(float(last["topk_ms"]), 4)},
+            "setup_s": {"generate": round(t_gen, 3), "pack": round(t_pack, 3)},
         }
-        if world == 1 and not args.no_host_inclusive:
-            out["host_inclusive"] = host_inclusive(swg, ctx, flat, off, K, cells_local)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(swg, q, flat, off, sc, lq)
-        print(json.dumps(out), flush=True)
-
+        if verify is not None:
+            block["verify"] = verify
+        if host_inclusive_leg and env.world == 1 and not a.no_host_inclusive:
+            block["host_inclusive"] = host_inclusive(env, ctx, flat, off, K, cells_local)
+        if cpu_leg and env.world == 1 and not a.no_cpu_baseline:
+            block["cpu_baseline"] = cpu_baseline(swg, q, flat, off, sc, lq)
     db.close()
     ctx.close()
-    if use_dist:
-        dist.destroy_process_group()
+    return block
 
 
-def host_inclusive(swg, ctx, flat, off, k, cells):
+def verify_topk(env, ctx, db, q, sc, flat, off, index, K, merger, timed_hits):
+    """Outside the timed region, once: the (merged) top-K against the int32 oracle.
+    (a) every candidate this rank contributed: oracle score == GPU score;
+    (b) a seeded sample of this rank's sequences: none of them beats the rank's K-th key without being in
+        its list (the list really is the top of the shard);
+    (c) N > 1: the all-reduce-max merge == gathering every rank's keys and sorting them, identical on all
+        ranks, and identical to what the timed steps returned."""
+    swg = env.swg
+    orc = swg_loader.oracle()
+    table = sc.table()
+    keys, _ = ctx.search_keys(db, K)
+    keys = keys[keys != 0]
+    local = [swg.key_hit(int(k)) for k in keys]                   # (score, global index), best first
+    n_local = len(off) - 1
+    pos_of = (lambda g: int(np.searchsorted(index, g))) if index is not None else (lambda g: int(g))
+
+    def oracle_scores(positions):
+        lens = [int(off[p + 1]) - int(off[p]) for p in positions]
+        sub_off = np.zeros(len(positions) + 1, dtype=np.uint64)
+        sub_off[1:] = np.cumsum(lens)
+        sub_flat = (np.concatenate([flat[int(off[p]):int(off[p + 1])] for p in positions])
+                    if positions else np.zeros(0, np.int8))
+        return orc.score_db(q, sub_flat, sub_off, table, -2, -1)
+
+    pos = [pos_of(g) for _, g in local]
+    want = oracle_scores(pos)
+    ok_a = all(int(w) == s for w, (s, _) in zip(want, local))
+    rng = np.random.default_rng(12345 + env.rank)
+    sample = [int(p) for p in rng.choice(n_local, size=min(64, n_local), replace=False)] if n_local else []
+    ss = oracle_scores(sample)
+    kth = int(keys[-1]) if len(keys) >= min(K, n_local) and len(keys) else 0
+    listed = set(g for _, g in local)
+    ok_b = True
+    for p, s in zip(sample, ss):
+        g = int(index[p]) if index is not None else p
+        if swg.hit_key(int(s), g) > kth and g not in listed:
+            ok_b = False
+    res = {"candidates_checked": len(local), "candidates_equal_oracle": bool(ok_a),
+           "sampled": len(sample), "sample_consistent_with_kth": bool(ok_b)}
+    ok = ok_a and ok_b
+    if env.use_dist:
+        torch, dist = env.torch, env.dist
+        mine = np.zeros(K, dtype=np.uint64)
+        mine[:len(keys)] = keys
+        merged = merger.merge_keys(mine)                          # the path the timed steps take
+        gathered = [torch.zeros(K, dtype=torch.int64, device="cuda") for _ in range(env.world)]
+        dist.all_gather(gathered, torch.from_numpy(mine.view(np.int64)).cuda())
+        allk = np.concatenate([g.cpu().numpy().view(np.uint64) for g in gathered])
+        allk = np.sort(allk[allk != 0])[::-1][:K]
+        plain = [swg.key_hit(int(k)) for k in allk]
+        ok_c = merged == plain and (timed_hits is None or list(timed_hits) == plain)
+        flag = torch.tensor([1 if (ok and ok_c) else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        res.update({"merge_equals_gather_and_sort": bool(ok_c), "all_ranks_ok": bool(int(flag.item()) == 1),
+                    "best": plain[:3]})
+        ok = ok and ok_c and int(flag.item()) == 1
+    else:
+        res["best"] = local[:3]
+        if timed_hits is not None:
+            res["timed_steps_returned_the_same"] = list(timed_hits) == local
+            ok = ok and res["timed_steps_returned_the_same"]
+    res["ok"] = bool(ok)
+    if not ok:
+        raise SystemExit("bench.py: top-K verification FAILED on rank %d: %s" % (env.rank, json.dumps(res)))
+    return res
+
+
+def host_inclusive(env, ctx, flat, off, k, cells):
     """The same search once from HOST buffers, outside the timed region and never `value`: pack the
-    sequences (host work), copy the packed shard over PCIe, build its per-database device tables,
-    fill, and copy every score back -- what a caller pays who searches a database exactly once."""
-    import torch
+    sequences (host work), copy the residue bytes over PCIe, build the per-database device tables on
+    the device, fill, and copy every score back -- what a caller pays who searches a database exactly once."""
+    swg = env.swg
     t0 = time.perf_counter()
     db = swg.Database(flat, off)
     t1 = time.perf_counter()
     db.upload(ctx)
-    torch.cuda.synchronize()
+    env.torch.cuda.synchronize()
     t2 = time.perf_counter()
     ctx.search(db, want_scores=True, k=k)
     t3 = time.perf_counter()
@@ -299,7 +442,8 @@ def host_inclusive(swg, ctx, flat, off, k, cells):
             "upload_bytes": nbytes, "first_search_ms": round((t3 - t2) * 1e3, 3),
             "next_search_ms": round((t4 - t3) * 1e3, 3),
             "gcups_upload_and_first_search": round(cells / (t3 - t1) / 1e9, 1),
-            "note": "the first search of a database builds its pair tokens on the host and uploads them; all scores are copied back"}
+            "note": "upload = residue bytes + 16 B per sequence; the first search builds the pair tokens on the device "
+                    "from them and plans the geometry; all scores are copied back"}
 
 
 class TopKMerger:
@@ -333,10 +477,21 @@ class TopKMerger:
         return self.swg.topk_merge_keys(self.stage.numpy().view(np.uint64), k)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(swg, q, flat, off, sc, lq):
     """The reference's own fill (oracle/_ref: its alignment.c compiled from its sources,
     dispatched as its driver does) on this host's cores, over a bounded sample of the
-    same database: whole 16-record groups, evenly spaced, about 3e10 cells."""
+    same database: whole 16-record groups, evenly spaced, about 3e10 cells; and on ONE thread over an
+    eighth of that sample (BASELINE.md section 3 asks for both, with the CPU model)."""
     orc = swg_loader.oracle()
     n = len(off) - 1
     groups = n // 16
@@ -346,13 +501,14 @@ def cpu_baseline(swg, q, flat, off, sc, lq):
     sel = np.unique(np.linspace(0, groups - 1, take).astype(np.int64))
     lens = np.diff(off.astype(np.int64))
     table = sc.table()
+    model = cpu_model()
     if orc.have_ref():
-        batches = []
-        cells = 0
+        batches, bcells = [], []
         for g in sel:
             seqs = [flat[int(off[i]):int(off[i + 1])] for i in range(g * 16, g * 16 + 16)]
             batches.append(orc.make_batch16(seqs))
-            cells += lq * int(lens[g * 16:g * 16 + 16].sum())
+            bcells.append(lq * int(lens[g * 16:g * 16 + 16].sum()))
+        cells = int(sum(bcells))
         # The reference takes omp_get_max_threads() threads (src/alignment_cmdline.c:341-347): all
         # hardware threads of the host.  This process may own fewer CPUs (cgroup quota, cpuset), so it is
         # timed with that many threads too and the better rate is the baseline.
@@ -363,10 +519,14 @@ def cpu_baseline(swg, q, flat, off, sc, lq):
         for t in sorted({hw, min(hw, share)}):
             _, secs = orc.ref_batches(q, batches, table, -2, -1, threads=t)
             runs[t] = cells / secs / 1e9
+        one = batches[::8]
+        _, secs1 = orc.ref_batches(q, one, table, -2, -1, threads=1)
+        one_thread = sum(bcells[::8]) / secs1 / 1e9
         best = max(runs, key=runs.get)
         return {"value": round(runs[best], 3), "unit": "GCUPS", "cores": int(best), "kind": "reference",
-                "sample": "%d of %d 16-record batches of the same DB (%.3g real cells), reference "
-                          "alignment_fill_matrices under its OpenMP dynamic dispatch, fill region only; "
+                "cpu_model": model, "one_thread_gcups": round(one_thread, 3),
+                "sample": "%d of %d 16-record batches of the same DB (%.3g real cells; one thread: every 8th of them), "
+                          "reference alignment_fill_matrices under its OpenMP dynamic dispatch, fill region only; "
                           "this process may use %d CPUs of the host's %d hardware threads; GCUPS by threads: %s"
                           % (len(batches), groups, cells, share, hw,
                              ", ".join("%d: %.1f" % (t, v) for t, v in sorted(runs.items())))}
@@ -379,8 +539,60 @@ def cpu_baseline(swg, q, flat, off, sc, lq):
     orc.score_db(q, sub_flat, sub_off, table, -2, -1)
     secs = time.perf_counter() - t0
     return {"value": round(lq * float(sub_off[-1]) / secs / 1e9, 3), "unit": "GCUPS",
-            "cores": os.cpu_count(), "kind": "port",
+            "cores": os.cpu_count(), "kind": "port", "cpu_model": model,
             "sample": "%d sequences of the same DB, scalar int32 oracle with OpenMP" % len(idx)}
+
+
+def line_from(block, env, scaling):
+    """The driver's one-line contract from a configuration's block."""
+    out = {"metric": METRIC, "value": block["value"], "unit": "GCUPS", "n_gpus": env.world,
+           "steps": block["steps"], "warmup": block["warmup"], "ms_per_step": block["ms_per_step"],
+           "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": block["dtype"],
+           "data": "synthetic", "config": block["config"], "roofline": block["roofline"],
+           "kernel_ms": block["kernel_ms"]}
+    for k in ("verify", "host_inclusive", "cpu_baseline"):
+        if k in block:
+            out[k] = block[k]
+    return out
+
+
+def main():
+    args = parse_args()
+    env = Env(args)
+    K, W = args.steps, args.warmup
+    if env.use_dist:
+        # one global database dealt by bins; total work fixed as the number of GPUs grows
+        cnum = args.config or SHARDED
+        n_full = args.nseq or CONFIGS[cnum].get("n_full", CONFIGS[cnum]["n"])
+        block = run_config(env, cnum, K, W, sharded=True, n_override=n_full)
+        if env.rank == 0:
+            print(json.dumps(line_from(block, env, "strong")), flush=True)
+    elif args.config:
+        block = run_config(env, args.config, K, W, host_inclusive_leg=True, cpu_leg=True)
+        out = line_from(block, env, "strong")
+        out["configs"] = {str(args.config): {k: v for k, v in block.items() if k not in ("cpu_baseline", "host_inclusive")}}
+        print(json.dumps(out), flush=True)
+    else:
+        # the headline first (exactly K timed steps after W warm-up steps), then the other shapes with
+        # step counts scaled to their step time so the whole run stays within minutes
+        blocks = {}
+        head = run_config(env, HEADLINE, K, W, cpu_leg=True)
+        blocks[str(HEADLINE)] = {k: v for k, v in head.items() if k != "cpu_baseline"}
+        out = line_from(head, env, "strong")
+        if not args.only_headline:
+            blocks["2"] = run_config(env, 2, K, W, host_inclusive_leg=True)
+            blocks["4"] = run_config(env, 4, max(2, K // 5), min(W, 2))
+            blocks["5"] = run_config(env, 5, max(2, K // 4), min(W, 2))
+            if "host_inclusive" in blocks["2"]:
+                out["host_inclusive"] = blocks["2"]["host_inclusive"]      # quoted on config 2, as in round 1
+            if not args.no_scaling_reference:
+                # config 4 whole (10M sequences) on this one GPU, through the sharded path with one shard:
+                # the N = 1 point of the strong-scaling curve the N > 1 runs continue
+                out["scaling_reference"] = run_config(env, SHARDED, 2, 1, sharded=True,
+                                                      n_override=CONFIGS[SHARDED]["n_full"])
+        out["configs"] = blocks
+        print(json.dumps(out), flush=True)
+    env.close()
 
 
 if __name__ == "__main__":

@@ -128,16 +128,26 @@ int swg_set_query(swg_ctx *ctx, const int8_t *idx, size_t lq);
 
 /* Host-only (needs no GPU).  Replaces the 16-lane transpose+pad packer of
  * reference src/alignment_cmdline.c:429-452: sequences are sorted by length
- * (descending, stable), grouped into bins of 128, and stored row-major as one
- * dword per 4 residues per sequence so that a wavefront's loads are coalesced.
+ * (descending, stable; the reference requires a pre-sorted input,
+ * src/alignment_cmdline.c:431-439) and stored as one byte per residue by sorted
+ * rank; 128 consecutive ranks form a bin, the unit of sharding.  That image is
+ * what swg_db_upload copies to the GPU; the kernels' own layouts are built from
+ * it on the device.
  * flat[offsets[i] .. offsets[i+1]) are the indices of sequence i.
  * shard_count > 1 keeps only bins b with b % shard_count == shard_rank of the
  * GLOBAL bin sequence (round-robin over GPUs: adjacent bins have near-equal
  * work); indices reported later are always original ones. */
 int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n,
                 int shard_rank, int shard_count, swg_db **out);
+/* The same for a shard that was cut elsewhere (a rank that generated or read only
+ * its own bins of a large database): the n_local sequences given are exactly the
+ * shard, global_index[i] is sequence i's index in the whole database of n_total
+ * sequences.  When they are the bins b % count == rank of the whole database's
+ * sorted order, in that order, the result equals swg_db_pack(whole, rank, count). */
+int swg_db_pack_shard(const int8_t *flat, const uint64_t *offsets, size_t n_local,
+                      const uint32_t *global_index, size_t n_total, swg_db **out);
 int swg_db_upload(swg_ctx *ctx, swg_db *db); /* H2D; db becomes resident on ctx's GPU */
-/* Packed-database file (host-only): the sorted, binned, dword-packed image of swg_db_pack,
+/* Packed-database file (host-only): the sorted, re-coded image of swg_db_pack,
  * so a large database is ingested once; swg_db_load validates the structure it reads. */
 int swg_db_save(const swg_db *db, const char *path);
 int swg_db_load(const char *path, swg_db **out);
@@ -145,7 +155,7 @@ void swg_db_free(swg_db *db);
 size_t swg_db_count(const swg_db *db);          /* sequences in this shard */
 size_t swg_db_total_count(const swg_db *db);    /* sequences given to swg_db_pack */
 uint64_t swg_db_residues(const swg_db *db);     /* sum of lengths in this shard */
-uint64_t swg_db_packed_bytes(const swg_db *db); /* bytes resident in HBM */
+uint64_t swg_db_packed_bytes(const swg_db *db); /* bytes swg_db_upload copies to the GPU */
 /* original index of the i-th sequence of this shard in its sorted order */
 const uint32_t *swg_db_order(const swg_db *db);
 

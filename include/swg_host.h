@@ -82,6 +82,18 @@ void swg_synth_query(uint64_t seed, size_t lq, int8_t *out);
 int swg_synth_db_similar(uint64_t seed, size_t n, double median, double sigma_ln, uint32_t min_len,
                          uint32_t max_len, const int8_t *query, size_t lq, double fraction,
                          double subst, int8_t **flat_out, uint64_t **offsets_out, size_t *n_planted);
+/* One shard of the same database without generating the rest: the sequences of the global bins
+ * (128 consecutive sorted ranks) b with b % shard_count == shard_rank -- exactly the bins
+ * swg_db_pack(..., shard_rank, shard_count) keeps of the whole database.  offsets_out[n_local+1]
+ * are over the shard alone; index_out[n_local] are the sequences' global indices (a sequence is
+ * seeded by its global sorted rank, so the union of all shards is byte for byte the database of
+ * swg_synth_db / swg_synth_db_similar with the same arguments); residues_total = sum of lengths
+ * of the WHOLE database.  fraction == 0: no planted copies (query may be NULL).  Feed the result
+ * to swg_db_pack_shard. */
+int swg_synth_db_shard(uint64_t seed, size_t n, double median, double sigma_ln, uint32_t min_len,
+                       uint32_t max_len, const int8_t *query, size_t lq, double fraction, double subst,
+                       int shard_rank, int shard_count, int8_t **flat_out, uint64_t **offsets_out,
+                       uint32_t **index_out, size_t *n_local, uint64_t *residues_total, size_t *n_planted);
 void swg_synth_free(void *p);
 
 /* Threads the host helpers' parallel loops use: the smallest of OpenMP's maximum (OMP_NUM_THREADS),

@@ -32,7 +32,7 @@ SWG_ERR_STATE, SWG_ERR_RESIDUE, SWG_ERR_IO, SWG_ERR_NODEVICE = -4, -5, -6, -7
 # every symbol declared in include/swg.h and include/swg_host.h
 ABI_SYMBOLS = [
     "swg_create", "swg_destroy", "swg_last_error", "swg_global_error", "swg_abi_version",
-    "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_upload",
+    "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_pack_shard", "swg_db_upload",
     "swg_db_free", "swg_db_save", "swg_db_load", "swg_db_count", "swg_db_total_count", "swg_db_residues",
     "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_search_begin", "swg_search_end",
     "swg_fill_batches16", "swg_align_hits", "swg_align_ops_bound", "swg_hit_key",
@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "swg_group_align_hits", "swg_group_align_ops_bound",
     "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
     "swg_scoring_load_matrix", "swg_query_sanitize", "swg_seqs_read", "swg_seqs_free",
-    "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar",
+    "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar", "swg_synth_db_shard",
     "swg_synth_free", "swg_host_threads",
 ]
 
@@ -116,6 +116,7 @@ _sig("swg_set_option", C.c_int, [_vp, C.c_char_p, C.c_long])
 _sig("swg_set_scoring", C.c_int, [_vp, _vp, C.c_int, C.c_int])
 _sig("swg_set_query", C.c_int, [_vp, _vp, C.c_size_t])
 _sig("swg_db_pack", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_vp)])
+_sig("swg_db_pack_shard", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(_vp)])
 _sig("swg_db_upload", C.c_int, [_vp, _vp])
 _sig("swg_db_free", None, [_vp])
 _sig("swg_db_save", C.c_int, [_vp, C.c_char_p])
@@ -160,7 +161,13 @@ _sig("swg_synth_query", None, [C.c_uint64, C.c_size_t, _vp])
 _sig("swg_synth_db_similar", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_double, C.c_uint32,
                                        C.c_uint32, _vp, C.c_size_t, C.c_double, C.c_double,
                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)])
+_sig("swg_synth_db_shard", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
+                                     _vp, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
+                                     C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)])
 _sig("swg_synth_free", None, [_vp])
+# test hook, declared in csrc/swg_host_internal.h (not part of the public ABI)
+_sig("swg_debug_pair_tokens", C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)])
 
 
 def _check(rc, ctx=None):
@@ -227,11 +234,34 @@ def read_seqs(path, max_records=0):
     return names, seq, idx, seq_off
 
 
+class _Owned:
+    """A buffer malloc'ed by the library, released with swg_synth_free when the last array over it dies."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+        self.buf = (C.c_uint8 * nbytes).from_address(ptr.value)
+
+    def __del__(self):
+        if self.ptr is not None:
+            lib.swg_synth_free(self.ptr)
+            self.ptr = None
+
+
 def _take(ptr, nbytes, dtype):
-    buf = (C.c_uint8 * nbytes).from_address(ptr.value) if nbytes else None
-    arr = np.frombuffer(buf, dtype=dtype).copy() if nbytes else np.zeros(0, dtype=dtype)
-    lib.swg_synth_free(ptr)
+    """numpy array over a library-owned buffer WITHOUT copying it (a 10M-sequence database is 3.8 GB);
+    the buffer is freed when the array (and every view of it) is gone."""
+    if not nbytes:
+        lib.swg_synth_free(ptr)
+        return np.zeros(0, dtype=dtype)
+    owner = _Owned(ptr, nbytes)
+    arr = np.frombuffer(owner.buf, dtype=dtype)     # keeps owner.buf alive ...
+    _OWNERS[id(owner.buf)] = owner                  # ... and the owner lives as long as its buffer does
+    import weakref
+    weakref.finalize(arr, _OWNERS.pop, id(owner.buf), None)
     return arr
+
+
+_OWNERS = {}
 
 
 def synth_db(seed, n, median=290.0, sigma_ln=0.75, min_len=20, max_len=5000, query=None,
@@ -250,6 +280,29 @@ def synth_db(seed, n, median=290.0, sigma_ln=0.75, min_len=20, max_len=5000, que
     offsets = _take(off, (n + 1) * 8, np.uint64)
     residues = _take(flat, int(offsets[n]), np.int8)
     return (residues, offsets) if planted is None else (residues, offsets, planted)
+
+
+def synth_db_shard(seed, n, shard_rank, shard_count, median=290.0, sigma_ln=0.75, min_len=20, max_len=5000,
+                   query=None, fraction=0.0, subst=0.05):
+    """One shard (global bins b % shard_count == shard_rank) of the database synth_db(seed, n, ...) would
+    return, without generating the rest -> dict(flat, offsets[n_local+1], index[n_local] global indices,
+    n_total, residues_total, planted)."""
+    flat, off, idx = _vp(), _vp(), _vp()
+    nl, tot, npl = C.c_size_t(0), C.c_uint64(0), C.c_size_t(0)
+    if query is not None and fraction > 0.0:
+        q, qp = _i8(query)
+        lq = len(q)
+    else:
+        qp, lq, fraction = None, 0, 0.0
+    _check(lib.swg_synth_db_shard(seed, n, median, sigma_ln, min_len, max_len, qp, lq, fraction, subst,
+                                  shard_rank, shard_count, C.byref(flat), C.byref(off), C.byref(idx),
+                                  C.byref(nl), C.byref(tot), C.byref(npl)))
+    n_local = nl.value
+    offsets = _take(off, (n_local + 1) * 8, np.uint64)
+    index = _take(idx, n_local * 4, np.uint32)
+    residues = _take(flat, int(offsets[n_local]), np.int8)
+    return dict(flat=residues, offsets=offsets, index=index, n_total=n, residues_total=int(tot.value),
+                planted=int(npl.value))
 
 
 def synth_query(seed, lq):
@@ -281,7 +334,9 @@ def topk_merge_keys(keys, k):
 class Database:
     """Host-packed database shard (swg_db); `upload(ctx)` makes it resident."""
 
-    def __init__(self, flat=None, offsets=None, shard_rank=0, shard_count=1, path=None):
+    def __init__(self, flat=None, offsets=None, shard_rank=0, shard_count=1, path=None, index=None, n_total=None):
+        """flat/offsets: the whole database, of which bins b % shard_count == shard_rank are kept; or, with
+        index (global index of every sequence given) and n_total, a shard that was cut elsewhere."""
         self.handle = None
         if path is not None:            # load a packed-database file written by save()
             h = _vp()
@@ -292,7 +347,13 @@ class Database:
         self._off = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = self._off.size - 1
         h = _vp()
-        _check(lib.swg_db_pack(fp, self._off.ctypes.data_as(_vp), n, shard_rank, shard_count, C.byref(h)))
+        if index is not None:
+            ix = np.ascontiguousarray(index, dtype=np.uint32)
+            assert ix.size == n
+            _check(lib.swg_db_pack_shard(fp, self._off.ctypes.data_as(_vp), n, ix.ctypes.data_as(_vp),
+                                         int(n_total), C.byref(h)))
+        else:
+            _check(lib.swg_db_pack(fp, self._off.ctypes.data_as(_vp), n, shard_rank, shard_count, C.byref(h)))
         self.handle = h
         self._flat = None  # the library copied what it needs
 
@@ -305,6 +366,15 @@ class Database:
         if self.count == 0:                 # a shard may hold nothing (fewer bins than shards)
             return np.zeros(0, dtype=np.uint32)
         return np.ctypeslib.as_array(lib.swg_db_order(self.handle), shape=(self.count,)).copy()
+
+    def debug_pair_tokens(self, ctx, from_host):
+        """Test hook: the pair-token image (uint32 dwords) built on the device or by the host builder."""
+        n = C.c_size_t(0)
+        _check(lib.swg_debug_pair_tokens(ctx.handle, self.handle, 1 if from_host else 0, None, 0, C.byref(n)), ctx.handle)
+        out = np.zeros(n.value, dtype=np.uint32)
+        _check(lib.swg_debug_pair_tokens(ctx.handle, self.handle, 1 if from_host else 0, out.ctypes.data_as(_vp),
+                                         out.size, C.byref(n)), ctx.handle)
+        return out
 
     def save(self, path):
         _check(lib.swg_db_save(self.handle, path.encode()))

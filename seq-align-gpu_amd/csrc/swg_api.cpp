@@ -252,6 +252,9 @@ void swg_db_release_device(swg_db *db)
 {
     if (!db || db->device < 0) return;
     (void)hipSetDevice(db->device);
+    (void)hipFree(db->d_codes);
+    (void)hipFree(db->d_code_off);
+    (void)hipFree(db->d_lens);
     (void)hipFree(db->d_packed);
     (void)hipFree(db->d_bin_off);
     (void)hipFree(db->d_bin_nblk);
@@ -277,6 +280,9 @@ void swg_db_release_device(swg_db *db)
         (void)hipFree(L.d_scratch);
         L = SwgDiagLayout();
     }
+    db->d_codes = nullptr;
+    db->d_code_off = nullptr;
+    db->d_lens = nullptr;
     db->d_packed = nullptr;
     db->d_bin_off = nullptr;
     db->d_bin_nblk = nullptr;
@@ -309,6 +315,10 @@ static int select_bufs(swg_ctx *ctx, swg_db *db, int slot)
     return SWG_OK;
 }
 
+// What crosses PCIe: one byte per residue (whole dwords per sequence) and 16 bytes per slot.  The
+// kernels' own layouts are built from that on the device: the pair tokens on the first search that
+// uses the diagonal engine's work queue (ensure_pair_tokens), the bin image only if an engine that
+// reads bins is ever used (ensure_bins).
 extern "C" int swg_db_upload(swg_ctx *ctx, swg_db *db)
 {
     if (!ctx || !db) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_db_upload: NULL argument");
@@ -317,27 +327,55 @@ extern "C" int swg_db_upload(swg_ctx *ctx, swg_db *db)
     db->device = ctx->device;
     const size_t nb = db->n_bins, ns = nb * SWG_BIN;
     int rc = [&]() -> int {
-        HIP_TRY(ctx, hipMalloc(&db->d_packed, std::max<size_t>(4, db->packed.size() * 4)));
-        HIP_TRY(ctx, hipMalloc(&db->d_bin_off, std::max<size_t>(8, nb * 8)));
-        HIP_TRY(ctx, hipMalloc(&db->d_bin_nblk, std::max<size_t>(4, nb * 4)));
+        std::vector<uint64_t> off_dw;
+        try {
+            off_dw.resize(ns + 1);
+        } catch (const std::exception &) {
+            return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_db_upload: out of host memory");
+        }
+        for (size_t i = 0; i <= ns; ++i) off_dw[i] = db->code_off[i] / 4;
+        HIP_TRY(ctx, hipMalloc(&db->d_codes, std::max<size_t>(4, db->codes.size())));
+        HIP_TRY(ctx, hipMalloc(&db->d_code_off, (ns + 1) * 8));
+        HIP_TRY(ctx, hipMalloc(&db->d_lens, std::max<size_t>(4, ns * 4)));
         HIP_TRY(ctx, hipMalloc(&db->d_order, std::max<size_t>(4, ns * 4)));
         int rb = select_bufs(ctx, db, 0);
         if (rb != SWG_OK) return rb;
-        if (nb) {
-            HIP_TRY(ctx, hipMemcpyAsync(db->d_packed, db->packed.data(), db->packed.size() * 4,
-                                        hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(db->d_bin_off, db->bin_off.data(), nb * 8,
-                                        hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(db->d_bin_nblk, db->bin_nblk.data(), nb * 4,
-                                        hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(db->d_order, db->order.data(), ns * 4, hipMemcpyHostToDevice,
-                                        ctx->stream));
+        if (!db->codes.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(db->d_codes, db->codes.data(), db->codes.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(db->d_code_off, off_dw.data(), (ns + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (ns) {
+            HIP_TRY(ctx, hipMemcpyAsync(db->d_lens, db->lens.data(), ns * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(db->d_order, db->order.data(), ns * 4, hipMemcpyHostToDevice, ctx->stream));
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // off_dw goes out of scope
+        db->upload_bytes = db->codes.size() + (ns + 1) * 8 + ns * 8;
         return SWG_OK;
     }();
     if (rc != SWG_OK) swg_db_release_device(db);
     return rc;
+}
+
+// The bin image: built on the device from the residue dwords the first time an engine that reads
+// bins is used on this database (the default engine never does).
+static int ensure_bins(swg_ctx *ctx, swg_db *db)
+{
+    if (db->d_packed || db->n_bins == 0) return SWG_OK;
+    const size_t nb = db->n_bins;
+    const uint64_t dwords = db->bin_off[nb - 1] + (uint64_t)db->bin_nblk[nb - 1] * SWG_BIN;
+    HIP_TRY(ctx, hipMalloc(&db->d_bin_off, nb * 8));
+    HIP_TRY(ctx, hipMalloc(&db->d_bin_nblk, nb * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(db->d_bin_off, db->bin_off.data(), nb * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(db->d_bin_nblk, db->bin_nblk.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *packed = nullptr;
+    HIP_TRY(ctx, hipMalloc(&packed, std::max<uint64_t>(4, dwords * 4)));
+    hipError_t e = swg_launch_build_bins(db->d_codes, db->d_code_off, db->d_lens, db->d_bin_off, db->d_bin_nblk,
+                                         (uint32_t)nb, packed, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(packed);
+        HIP_TRY(ctx, e);
+    }
+    db->d_packed = packed;
+    return SWG_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -459,28 +497,66 @@ static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, int cls, const SwgDiagPl
     return SWG_OK;
 }
 
-// Pair-major tokens, built once per database on first use by the diagonal engine.
+// Pair-major tokens, built once per database on first use by the diagonal engine: the block
+// offsets of the pairs on the host (they follow from the lengths alone, and the planner wants them
+// too), the tokens themselves on the device from the resident residue dwords.
 static int ensure_pair_tokens(swg_ctx *ctx, swg_db *db)
 {
     SwgPairTokens &T = db->ptok;
     if (T.tried) return SWG_OK;
     T.tried = true;
-    std::unique_ptr<uint32_t[]> tok;
-    size_t tok_dwords = 0;
     try {
-        if (swg_build_pair_tokens(db, &tok, &tok_dwords, &T.pair_blocks_prefix) != 0) return SWG_OK; // too large: static streams
-    } catch (const std::bad_alloc &) {
+        if (swg_build_pair_tokens(db, nullptr, nullptr, &T.pair_blocks_prefix) != 0) return SWG_OK; // too large: static streams
+    } catch (const std::exception &) {
         return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "pair tokens: out of host memory");
     }
     T.total_blocks = T.pair_blocks_prefix.back();
-    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(8, tok_dwords * 4)));
+    const uint32_t n_pairs = (uint32_t)(T.pair_blocks_prefix.size() - 1);
+    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(8, (size_t)T.total_blocks * 8)));
     HIP_TRY(ctx, hipMalloc(&T.d_pair_off, T.pair_blocks_prefix.size() * 4));
-    if (tok_dwords)
-        HIP_TRY(ctx, hipMemcpyAsync(T.d_tok, tok.get(), tok_dwords * 4, hipMemcpyHostToDevice, ctx->stream));
+    // (the host vector lives as long as the database: no wait needed for the copy)
     HIP_TRY(ctx, hipMemcpyAsync(T.d_pair_off, T.pair_blocks_prefix.data(), T.pair_blocks_prefix.size() * 4,
                                 hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, swg_launch_build_tokens(db->d_codes, db->d_code_off, db->d_lens, T.d_pair_off, n_pairs, T.total_blocks,
+                                         T.d_tok, ctx->stream));
     T.ok = true;
+    return SWG_OK;
+}
+
+// Test hook (not part of the public ABI, declared in swg_host_internal.h): the pair-token image of
+// a resident database as the device built it (from_host = 0) or as the host restatement of the
+// same layout builds it (from_host = 1).  *n_dwords = size of the image; copied when it fits cap.
+extern "C" int swg_debug_pair_tokens(swg_ctx *ctx, swg_db *db, int from_host, uint32_t *out, size_t cap_dwords,
+                                     size_t *n_dwords)
+{
+    if (!ctx || !db || !n_dwords) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_debug_pair_tokens: NULL argument");
+    *n_dwords = 0;
+    if (from_host) {
+        std::unique_ptr<uint32_t[]> tok;
+        std::vector<uint32_t> off;
+        size_t n = 0;
+        try {
+            if (swg_build_pair_tokens(db, &tok, &n, &off) != 0)
+                return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_debug_pair_tokens: database too large for pair tokens");
+        } catch (const std::exception &) {
+            return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_debug_pair_tokens: out of host memory");
+        }
+        *n_dwords = n;
+        if (out && n <= cap_dwords) memcpy(out, tok.get(), n * 4);
+        return SWG_OK;
+    }
+    if (db->device != ctx->device || !db->d_codes)
+        return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_debug_pair_tokens: database is not resident");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = ensure_pair_tokens(ctx, db);
+    if (rc != SWG_OK) return rc;
+    if (!db->ptok.ok) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_debug_pair_tokens: database too large for pair tokens");
+    const size_t n = (size_t)db->ptok.total_blocks * 2;
+    *n_dwords = n;
+    if (out && n <= cap_dwords && n) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, db->ptok.d_tok, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return SWG_OK;
 }
 
@@ -750,8 +826,9 @@ static int launch_systolic(swg_ctx *ctx, const swg_db *db, const Plan &pl, int g
 
 static int prepare_systolic(swg_ctx *ctx, const swg_db *db, const Plan &pl)
 {
-    int rc = ensure_profile(ctx, pl);
+    int rc = ensure_bins(ctx, const_cast<swg_db *>(db));
     if (rc != SWG_OK) return rc;
+    if ((rc = ensure_profile(ctx, pl)) != SWG_OK) return rc;
     const size_t need = pl.npass > 1 ? (size_t)pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * pl.info.nb : 0;
     return ensure_scratch(ctx, need);
 }
@@ -915,7 +992,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     if (!ctx || !db) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search: NULL argument");
     if (!ctx->have_scoring) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: no scoring set");
     if (ctx->query.empty()) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: no query set");
-    if (db->device != ctx->device || !db->d_packed)
+    if (db->device != ctx->device || !db->d_codes)
         return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: database is not resident on device %d",
                                  ctx->device);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1054,6 +1131,9 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             need = std::max(need, (size_t)re_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * re_pl.info.nb);
         if ((rc = ensure_scratch(ctx, need)) != SWG_OK) return rc;
     }
+
+    // the systolic engine and the int32 kernels read the bin image (built on the device on first use)
+    if ((!use_diag || may_saturate) && (rc = ensure_bins(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
 
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[0], s));

@@ -293,9 +293,11 @@ static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint16_t *t)
     const uint32_t both = std::min(lx, ly); // (= ly: sorted order)
     for (uint32_t j = 0; j < both; ++j) r[j] = (uint16_t)(cx[j] | (uint32_t)cy[j] << 8);
     for (uint32_t j = both; j < lx; ++j) r[j] = cx[j];
-    if (lx) r[lx - 1] |= 2u; // last row of the pair
     const uint64_t blocks = (2ull + lx + 3) / 4;
     for (uint64_t j = 2ull + lx; j < blocks * 4; ++j) t[j] = 0; // rest of the last block: padding rows
+    // last row of the pair: X's last residue; for an empty pair the second reset row, so that every
+    // pair hands its id to the tail lane exactly once
+    t[lx + 1] |= 2u;
     return blocks;
 }
 
@@ -369,7 +371,7 @@ void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_
 int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, size_t *tok_dwords,
                           std::vector<uint32_t> *pair_off)
 {
-    *tok_dwords = 0;
+    if (tok_dwords) *tok_dwords = 0;
     const uint64_t n_pairs = swg_db_pair_count(db);
     if (n_pairs >= (1ull << 31)) return -1;
     pair_off->assign((size_t)n_pairs + 1, 0u);
@@ -379,6 +381,7 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
         if (total >= (1ull << 32)) return -1; // block offsets are 32-bit on the device
         (*pair_off)[p + 1] = (uint32_t)total;
     }
+    if (!tok) return 0; // offsets only: the tokens themselves are built on the device
     // every pair writes all rows of its blocks, so the buffer needs no zero fill: its pages are
     // first touched by the threads that fill them
     tok->reset(new uint32_t[std::max<size_t>(2, (size_t)total * 2)]);

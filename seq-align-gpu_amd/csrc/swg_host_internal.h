@@ -62,6 +62,7 @@ struct SwgDiagLayout {
 // order owns blocks [pair_off[p], pair_off[p+1]); independent of the launch geometry.
 struct SwgPairTokens {
     bool tried = false, ok = false;
+    bool host_built = false; // diagnostics: tokens came from the host builder (option "host_tokens")
     uint64_t total_blocks = 0;
     uint2 *d_tok = nullptr;
     uint32_t *d_pair_off = nullptr;
@@ -95,29 +96,38 @@ struct SwgTuned {
 };
 
 struct swg_db {
-    // host image
-    size_t n_total = 0;             // sequences given to swg_db_pack
+    // host image: what swg_db_pack builds and swg_db_save writes.  Sequences by sorted rank (length
+    // descending, stable); 128 consecutive ranks form a bin (the unit of sharding and of the systolic
+    // engine); the last bin of a shard may have empty slots (order = ~0, length 0).
+    size_t n_total = 0;             // sequences of the whole database
     size_t n_local = 0;             // sequences of this shard
     uint32_t n_bins = 0;            // bins of this shard
     uint32_t max_nblk = 0;          // row-blocks of the longest bin
     uint64_t residues = 0;          // sum of lengths (this shard)
-    uint64_t rows_padded = 0;       // sum over bins of nblk*4*128 (rows actually walked)
-    std::vector<uint64_t> bin_off;  // [n_bins] dword offset into packed
+    uint64_t rows_padded = 0;       // sum over bins of nblk*4*128 (rows the bin-based kernels walk)
+    std::vector<uint64_t> bin_off;  // [n_bins] dword offset of a bin in the device bin image
     std::vector<uint32_t> bin_nblk; // [n_bins]
     std::vector<uint32_t> order;    // [n_bins*128] original index of each slot, ~0u = empty
     std::vector<uint32_t> lens;     // [n_bins*128]
-    std::vector<uint32_t, SwgNoInit<uint32_t>> packed; // residue dwords (bins, systolic engine)
-    std::vector<uint8_t, SwgNoInit<uint8_t>> codes;    // residue bytes (index<<3) by sorted rank, back to back
-    std::vector<uint64_t> code_off; // [n_bins*128+1]
+    // residue bytes (index<<3) by sorted rank; every sequence starts on a 4-byte boundary and is
+    // filled up to one with the padding residue 0, so that a sequence is a run of whole dwords
+    std::vector<uint8_t, SwgNoInit<uint8_t>> codes;
+    std::vector<uint64_t> code_off; // [n_bins*128+1] byte offsets into codes (multiples of 4)
     SwgPairTokens ptok;             // pair-major tokens (work-queue form of the diagonal engine)
     SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs
     std::map<uint64_t, SwgTuned> tuned; // query length -> engine + geometry that measured fastest on this device
-    // device image (valid after swg_db_upload)
+    // device image (valid after swg_db_upload): the residue bytes and three words per slot; the pair
+    // tokens (ptok) and the bin image are built FROM them on the device, the bins only when an
+    // engine that reads them is used (swg_ensure_bins)
     int device = -1;
-    uint32_t *d_packed = nullptr;
+    uint32_t *d_codes = nullptr;    // codes as dwords
+    uint64_t *d_code_off = nullptr; // [n_slots+1] DWORD offsets into d_codes
+    uint32_t *d_lens = nullptr;     // [n_slots]
+    uint32_t *d_order = nullptr;    // [n_slots]
+    uint32_t *d_packed = nullptr;   // bin image (systolic engine, int32 kernels): lazily built
     uint64_t *d_bin_off = nullptr;
     uint32_t *d_bin_nblk = nullptr;
-    uint32_t *d_order = nullptr;
+    uint64_t upload_bytes = 0;      // bytes the last swg_db_upload copied over PCIe
     // per-search output buffers, one set per in-flight slot (allocated on first use); the
     // plain members below point at the set of the search being queued
     struct Bufs {
@@ -190,6 +200,9 @@ int swg_set_global_error(int code, const char *fmt, ...) __attribute__((format(p
 int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
     __attribute__((format(printf, 3, 4)));
 void swg_db_release_device(swg_db *db);
+// test hook: the pair-token image as the device built it, or as the host restatement builds it
+extern "C" int swg_debug_pair_tokens(swg_ctx *ctx, swg_db *db, int from_host, uint32_t *out, size_t cap_dwords,
+                                     size_t *n_dwords);
 
 // swg_diag_host.cpp (host only)
 // geometry of both classes for one query length on one device; returns the number of
@@ -200,7 +213,9 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
 int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
                              long opt_long_split, bool allow_split, bool work_queue,
                              std::vector<SwgDiagWork> *cands);
-// 0 on success; -1 when the database is too large for 32-bit block offsets
+// 0 on success; -1 when the database is too large for 32-bit block offsets.  tok == NULL: only
+// pair_off (the tokens themselves are built on the device, swg_launch_build_tokens); otherwise also
+// the host builder's token image, which the tests compare the device's with.
 int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, size_t *tok_dwords,
                           std::vector<uint32_t> *pair_off);
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Database layout in HBM (built by swg_db_pack, swg_pack.cpp):
+// Bin image in HBM (built on the device by swg_build_bins_kernel when an engine that reads it is used):
 //   sequences sorted by length (descending), 128 consecutive ones form a BIN;
 //   a bin of nblk row-blocks is nblk*128 dwords:  dword[blk*128 + SWG_BIN_COLUMN(rank)]
 //   holds rows 4*blk..4*blk+3 of the bin's rank-th sequence, one byte per row, byte = index<<3
@@ -115,6 +115,15 @@ hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
                                     uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols, int k_real,
                                     int k_padded, uint8_t *d_profile, hipStream_t stream);
 int swg_diag_padded_cols(int K); // layout columns of a lane's slice
+
+// Per-database layouts from the uploaded residue dwords (d_code_off in dwords): the pair-major
+// token array of the diagonal engine, and the bin image of the systolic engine / int32 kernels.
+hipError_t swg_launch_build_tokens(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
+                                   const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint2 *d_tok,
+                                   hipStream_t stream);
+hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
+                                 const uint64_t *d_bin_off, const uint32_t *d_bin_nblk, uint32_t n_bins,
+                                 uint32_t *d_packed, hipStream_t stream);
 
 // Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, or 65535 in the wide form) to list.
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling,

@@ -1010,6 +1010,81 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
         reinterpret_cast<int32_t *>(out)[e] = pad ? -(1 << 29) : v;
 }
 
+// ---------------------------------------------------------------------------
+// per-database layouts, built on the device from the uploaded residue bytes
+// ---------------------------------------------------------------------------
+// What goes over PCIe is one byte per residue (every sequence a run of whole dwords, the rest of
+// its last dword holding the padding residue 0) and three words per sequence.  The layouts the
+// fill kernels read are made from that here, at HBM speed, instead of on the host.
+//
+// Pair tokens (diagonal engine): thread b writes 4-row block b of the pair-major token array.
+// Block k of a pair holds the rows 4k .. 4k+3 of its token stream = two reset rows, then one row
+// per residue of the longer sequence X (row r: residue r - 2), i.e. residues 4k-2 .. 4k+1: the
+// upper half of residue dword k-1 and the lower half of dword k.  Flag bit 1 (last row) goes on
+// the row of X's last residue -- for an empty pair on the second reset row, so that every pair
+// hands its id to the tail lane exactly once.
+__global__ void swg_build_tokens_kernel(const uint32_t *codes, const uint64_t *code_off, const uint32_t *lens,
+                                        const uint32_t *pair_off, uint32_t n_pairs, uint2 *tok)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_pairs == 0u || b >= (uint64_t)pair_off[n_pairs]) return;
+    uint32_t lo = 0u, hi = n_pairs; // pair_off[lo] <= b < pair_off[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if ((uint64_t)pair_off[mid] <= b) lo = mid; else hi = mid;
+    }
+    const uint32_t k = (uint32_t)(b - pair_off[lo]);
+    const uint32_t sx = 2u * lo, sy = sx + 1u;
+    const uint32_t lx = lens[sx], ly = lens[sy];
+    const uint32_t *cx = codes + code_off[sx], *cy = codes + code_off[sy];
+    const uint32_t ndx = (lx + 3u) / 4u, ndy = (ly + 3u) / 4u;
+    const uint32_t x1 = k < ndx ? cx[k] : 0u, x0 = (k >= 1u && k - 1u < ndx) ? cx[k - 1u] : 0u;
+    const uint32_t y1 = k < ndy ? cy[k] : 0u, y0 = (k >= 1u && k - 1u < ndy) ? cy[k - 1u] : 0u;
+    const uint32_t xw = (x1 << 16) | (x0 >> 16), yw = (y1 << 16) | (y0 >> 16);
+    uint32_t t01 = __builtin_amdgcn_perm(yw, xw, 0x05010400u); // rows 0,1: X byte | Y byte << 8 each
+    uint32_t t23 = __builtin_amdgcn_perm(yw, xw, 0x07030602u); // rows 2,3
+    if (k == 0u) t01 |= SWG_TOK_RESET | (SWG_TOK_RESET << 16);
+    const uint32_t last = lx + 1u; // row of X's last residue
+    if (last / 4u == k) {
+        const uint32_t r = last & 3u;
+        if (r < 2u) t01 |= SWG_TOK_LAST << (16u * r); else t23 |= SWG_TOK_LAST << (16u * (r - 2u));
+    }
+    tok[b] = make_uint2(t01, t23);
+}
+
+// Bin image (systolic engine, bin-based int32 kernel): one workgroup per bin, thread s = slot s of
+// the bin; dword[blk*128 + SWG_BIN_COLUMN(s)] = residue dword blk of that sequence (0 past its end).
+__global__ void swg_build_bins_kernel(const uint32_t *codes, const uint64_t *code_off, const uint32_t *lens,
+                                      const uint64_t *bin_off, const uint32_t *bin_nblk, uint32_t *packed)
+{
+    const uint32_t bin = blockIdx.x, s = threadIdx.x;
+    const uint32_t slot = bin * SWG_BIN + s;
+    const uint32_t nd = (lens[slot] + 3u) / 4u, nblk = bin_nblk[bin];
+    const uint32_t *c = codes + code_off[slot];
+    uint32_t *out = packed + bin_off[bin] + SWG_BIN_COLUMN(s);
+    for (uint32_t blk = 0; blk < nblk; ++blk) out[(size_t)blk * SWG_BIN] = blk < nd ? c[blk] : 0u;
+}
+
+hipError_t swg_launch_build_tokens(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
+                                   const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint2 *d_tok,
+                                   hipStream_t stream)
+{
+    if (n_pairs == 0 || total_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_build_tokens_kernel, dim3((uint32_t)((total_blocks + 255) / 256)), dim3(256), 0, stream,
+                       d_codes, d_code_off, d_lens, d_pair_off, n_pairs, d_tok);
+    return hipGetLastError();
+}
+
+hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
+                                 const uint64_t *d_bin_off, const uint32_t *d_bin_nblk, uint32_t n_bins,
+                                 uint32_t *d_packed, hipStream_t stream)
+{
+    if (n_bins == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_build_bins_kernel, dim3(n_bins), dim3(SWG_BIN), 0, stream, d_codes, d_code_off, d_lens,
+                       d_bin_off, d_bin_nblk, d_packed);
+    return hipGetLastError();
+}
+
 __global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, int32_t ceiling, uint32_t *list,
                                              uint32_t *count)
 {

@@ -3,9 +3,11 @@
 // Replaces what the reference does per 16 records at
 // src/alignment_cmdline.c:429-452 (letters -> indices, transpose to [j][lane],
 // pad with '*'): here the whole database is sorted by length once (the
-// reference instead REQUIRES a pre-sorted input, src/alignment_cmdline.c:431-439),
-// cut into bins of 128 sequences and stored row-block-major, one dword per four
-// residues per sequence, padding = residue 0.
+// reference instead REQUIRES a pre-sorted input, src/alignment_cmdline.c:431-439)
+// and stored as residue bytes (index << 3) by sorted rank, every sequence a run
+// of whole dwords (filled up with the padding residue 0).  That array, the
+// lengths and the original indices are all that is copied to the GPU; the
+// kernels' own layouts (pair tokens, bins) are built from them on the device.
 #include "swg_host_internal.h"
 #include "../../include/swg_host.h"
 
@@ -13,21 +15,63 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <vector>
 
-extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n, int shard_rank,
-                           int shard_count, swg_db **out)
+// Bins, slot tables and offsets from the lengths by sorted slot (db->lens, db->order filled in).
+static void derive_tables(swg_db *db)
+{
+    const size_t nb = db->n_bins, ns = nb * SWG_BIN;
+    db->bin_off.resize(nb);
+    db->bin_nblk.resize(nb);
+    uint64_t dwords = 0, residues = 0, rows_padded = 0;
+    size_t n_local = 0;
+    for (size_t lb = 0; lb < nb; ++lb) {
+        const uint64_t len0 = db->lens[lb * SWG_BIN]; // sorted: the first of a bin is its longest
+        const uint32_t nblk = (uint32_t)std::max<uint64_t>(1, (len0 + SWG_ROWS_PER_BLK - 1) / SWG_ROWS_PER_BLK);
+        db->bin_off[lb] = dwords;
+        db->bin_nblk[lb] = nblk;
+        dwords += (uint64_t)nblk * SWG_BIN;
+        rows_padded += (uint64_t)nblk * SWG_ROWS_PER_BLK * SWG_BIN;
+    }
+    db->code_off.assign(ns + 1, 0);
+    for (size_t i = 0; i < ns; ++i) {
+        db->code_off[i + 1] = db->code_off[i] + ((uint64_t)db->lens[i] + 3) / 4 * 4;
+        residues += db->lens[i];
+        n_local += db->order[i] != 0xFFFFFFFFu;
+    }
+    db->n_local = n_local;
+    db->residues = residues;
+    db->rows_padded = rows_padded;
+    db->max_nblk = nb ? *std::max_element(db->bin_nblk.begin(), db->bin_nblk.end()) : 0;
+}
+
+// global_index: NULL (the sequences given ARE the database, index = position), or the original
+// index of each sequence given (a shard that was cut elsewhere: swg_db_pack_shard); n_total: size
+// of the whole database the indices refer to.
+static int pack_impl(const int8_t *flat, const uint64_t *offsets, size_t n, const uint32_t *global_index,
+                     size_t n_total, int shard_rank, int shard_count, swg_db **out)
 {
     if (!out) return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: out is NULL");
     *out = nullptr;
-    if ((!flat && n > 0 && offsets && offsets[n] > 0) || (!offsets && n > 0))
-        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: NULL input");
+    if (!offsets && n > 0) return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: NULL input");
     if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count)
         return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: bad shard %d/%d", shard_rank,
                                     shard_count);
     if (n >= 0xFFFFFFF0ull)
         return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: too many sequences");
+    swg_db *db = new (std::nothrow) swg_db();
+    if (!db) return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
+    std::unique_ptr<swg_db> holder(db); // freed on every error path, exceptions included
+    db->n_total = n_total;
+    if (n == 0) { // nothing to read: offsets may be NULL
+        derive_tables(db);
+        *out = holder.release();
+        return SWG_OK;
+    }
+    if (!flat && offsets[n] > offsets[0])
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: NULL input");
 
     // lengths + validation (the reference exits in letters_to_index on anything
     // outside A-Z/a-z/'*'; here an index outside 1..31 is an error code)
@@ -39,7 +83,7 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
     }
     if (max_len > 0x3FFFFFFFull)
         return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: sequence too long");
-    const uint64_t total = n ? offsets[n] - offsets[0] : 0;
+    const uint64_t total = offsets[n] - offsets[0];
     {
         int bad = 0;
 #pragma omp parallel for schedule(static) reduction(| : bad) num_threads(swg_host_threads())
@@ -51,10 +95,6 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
             return swg_set_global_error(SWG_ERR_RESIDUE,
                                         "swg_db_pack: residue index outside 1..31 in database");
     }
-
-    swg_db *db = new (std::nothrow) swg_db();
-    if (!db) return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
-    db->n_total = n;
 
     // stable counting sort by length, descending
     std::vector<uint32_t> sorted(n);
@@ -72,85 +112,76 @@ extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n
         my_bins.push_back(b);
     const size_t nb = my_bins.size();
     db->n_bins = (uint32_t)nb;
-    db->bin_off.resize(nb);
-    db->bin_nblk.resize(nb);
     db->order.assign(nb * SWG_BIN, 0xFFFFFFFFu);
     db->lens.assign(nb * SWG_BIN, 0u);
-    uint64_t dwords = 0;
-    uint64_t residues = 0, rows_padded = 0;
-    size_t n_local = 0;
+    std::vector<uint32_t> src_of(nb * SWG_BIN, 0u); // position of a slot's sequence in the caller's arrays
     for (size_t lb = 0; lb < nb; ++lb) {
         const size_t first = my_bins[lb] * SWG_BIN;
-        const uint64_t len0 = offsets[sorted[first] + 1] - offsets[sorted[first]];
-        const uint32_t nblk = (uint32_t)std::max<uint64_t>(1, (len0 + SWG_ROWS_PER_BLK - 1) / SWG_ROWS_PER_BLK);
-        db->bin_off[lb] = dwords;
-        db->bin_nblk[lb] = nblk;
-        dwords += (uint64_t)nblk * SWG_BIN;
-        rows_padded += (uint64_t)nblk * SWG_ROWS_PER_BLK * SWG_BIN;
         for (size_t s = 0; s < SWG_BIN && first + s < n; ++s) {
             const uint32_t oi = sorted[first + s];
-            db->order[lb * SWG_BIN + s] = oi;
-            const uint32_t len = (uint32_t)(offsets[oi + 1] - offsets[oi]);
-            db->lens[lb * SWG_BIN + s] = len;
-            residues += len;
-            ++n_local;
+            src_of[lb * SWG_BIN + s] = oi;
+            db->order[lb * SWG_BIN + s] = global_index ? global_index[oi] : oi;
+            db->lens[lb * SWG_BIN + s] = (uint32_t)(offsets[oi + 1] - offsets[oi]);
         }
     }
-    db->n_local = n_local;
-    db->residues = residues;
-    db->rows_padded = rows_padded;
-    db->max_nblk = nb ? *std::max_element(db->bin_nblk.begin(), db->bin_nblk.end()) : 0;
-    try {
-        db->packed.resize(dwords); // every bin zeroes its own blocks in the parallel loop below
-    } catch (const std::bad_alloc &) {
-        delete db;
-        return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory (%llu dwords)",
-                                    (unsigned long long)dwords);
+    derive_tables(db);
+    db->codes.resize(db->code_off.back()); // written completely, sequence by sequence, below
+    const long long ns = (long long)(nb * SWG_BIN);
+#pragma omp parallel for schedule(dynamic, 512) num_threads(swg_host_threads())
+    for (long long s = 0; s < ns; ++s) {
+        if (db->order[s] == 0xFFFFFFFFu) continue;
+        const int8_t *src = flat + offsets[src_of[s]];
+        const uint32_t len = db->lens[s];
+        uint8_t *cd = db->codes.data() + db->code_off[s];
+        for (uint32_t j = 0; j < len; ++j) cd[j] = (uint8_t)((uint8_t)src[j] << 3);
+        for (uint32_t j = len; j < (len + 3) / 4 * 4; ++j) cd[j] = 0; // padding residue up to the dword
     }
-
-    try {
-        db->code_off.assign(nb * SWG_BIN + 1, 0);
-        for (size_t i = 0; i < nb * SWG_BIN; ++i) db->code_off[i + 1] = db->code_off[i] + db->lens[i];
-        db->codes.resize(residues); // written completely, sequence by sequence, below
-    } catch (const std::bad_alloc &) {
-        delete db;
-        return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
-    }
-
-    uint32_t *pk = db->packed.data();
-#pragma omp parallel for schedule(dynamic, 4) num_threads(swg_host_threads())
-    for (long long lb = 0; lb < (long long)nb; ++lb) {
-        uint32_t *base = pk + db->bin_off[lb];
-        memset(base, 0, (size_t)db->bin_nblk[lb] * SWG_BIN * sizeof(uint32_t)); // padding rows and empty slots
-        for (size_t s = 0; s < SWG_BIN; ++s) {
-            const uint32_t oi = db->order[lb * SWG_BIN + s];
-            if (oi == 0xFFFFFFFFu) continue;
-            const int8_t *src = flat + offsets[oi];
-            const uint32_t len = db->lens[lb * SWG_BIN + s];
-            uint8_t *cd = db->codes.data() + db->code_off[lb * SWG_BIN + s];
-            for (uint32_t j = 0; j < len; ++j) cd[j] = (uint8_t)((uint8_t)src[j] << 3);
-            for (uint32_t j = 0; j < len; j += 4) {
-                uint32_t wd = 0;
-                const uint32_t m = std::min<uint32_t>(4, len - j);
-                for (uint32_t r = 0; r < m; ++r) wd |= ((uint32_t)(uint8_t)src[j + r] << 3) << (8 * r);
-                base[(size_t)(j / 4) * SWG_BIN + SWG_BIN_COLUMN((uint32_t)s)] = wd;
-            }
-        }
-    }
-    *out = db;
+    *out = holder.release();
     return SWG_OK;
 }
 
+// No C++ exception crosses the ABI: allocation failures and length errors of the containers
+// become SWG_ERR_NOMEM.
+template <class F> static int guarded(const char *what, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return swg_set_global_error(SWG_ERR_NOMEM, "%s: out of memory", what);
+    } catch (const std::exception &e) {
+        return swg_set_global_error(SWG_ERR_NOMEM, "%s: %s", what, e.what());
+    }
+}
+
+extern "C" int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n, int shard_rank,
+                           int shard_count, swg_db **out)
+{
+    return guarded("swg_db_pack", [&] { return pack_impl(flat, offsets, n, nullptr, n, shard_rank, shard_count, out); });
+}
+
+extern "C" int swg_db_pack_shard(const int8_t *flat, const uint64_t *offsets, size_t n_local,
+                                 const uint32_t *global_index, size_t n_total, swg_db **out)
+{
+    if (n_local > 0 && !global_index)
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack_shard: global_index is NULL");
+    if (n_local > n_total || n_total >= 0xFFFFFFF0ull)
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack_shard: %zu sequences of a database of %zu", n_local, n_total);
+    for (size_t i = 0; i < n_local; ++i)
+        if (global_index[i] >= n_total)
+            return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack_shard: index %u at %zu outside the database", global_index[i], i);
+    return guarded("swg_db_pack_shard", [&] { return pack_impl(flat, offsets, n_local, global_index, n_total, 0, 1, out); });
+}
+
 // ---------------------------------------------------------------------------
-// packed database file: the host image of a swg_db, written once (sorting, binning and
-// dword-packing are the expensive part of ingest), loaded with plain reads afterwards
+// packed database file: the host image of a swg_db (sorting and re-coding are the expensive
+// part of ingest), loaded with plain reads afterwards.  Layout: header, order[n_slots],
+// lens[n_slots], codes.
 // ---------------------------------------------------------------------------
 namespace {
-const char kMagic[8] = {'S', 'W', 'G', 'D', 'B', '0', '1', '\0'};
+const char kMagic[8] = {'S', 'W', 'G', 'D', 'B', '0', '2', '\0'};
 struct FileHeader {
     char magic[8];
-    uint64_t n_total, n_local, n_bins, max_nblk, residues, rows_padded;
-    uint64_t n_packed, n_codes;
+    uint64_t n_total, n_local, n_bins, residues, n_codes, reserved[3];
 };
 template <class V> bool put(FILE *f, const V &v)
 {
@@ -174,22 +205,16 @@ extern "C" int swg_db_save(const swg_db *db, const char *path)
     h.n_total = db->n_total;
     h.n_local = db->n_local;
     h.n_bins = db->n_bins;
-    h.max_nblk = db->max_nblk;
     h.residues = db->residues;
-    h.rows_padded = db->rows_padded;
-    h.n_packed = db->packed.size();
     h.n_codes = db->codes.size();
-    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && put(f, db->bin_off) && put(f, db->bin_nblk) && put(f, db->order) &&
-              put(f, db->lens) && put(f, db->code_off) && put(f, db->codes) && put(f, db->packed);
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && put(f, db->order) && put(f, db->lens) && put(f, db->codes);
     ok = (fclose(f) == 0) && ok;
     if (!ok) return swg_set_global_error(SWG_ERR_IO, "swg_db_save: short write to %s", path);
     return SWG_OK;
 }
 
-extern "C" int swg_db_load(const char *path, swg_db **out)
+static int load_impl(const char *path, swg_db **out)
 {
-    if (!path || !out) return swg_set_global_error(SWG_ERR_ARG, "swg_db_load: NULL argument");
-    *out = nullptr;
     FILE *f = fopen(path, "rb");
     if (!f) return swg_set_global_error(SWG_ERR_IO, "swg_db_load: cannot read %s", path);
     FileHeader h;
@@ -197,8 +222,18 @@ extern "C" int swg_db_load(const char *path, swg_db **out)
         fclose(f);
         return swg_set_global_error(SWG_ERR_IO, "swg_db_load: %s is not a packed database", path);
     }
-    const uint64_t ns = h.n_bins * SWG_BIN;
-    if (h.n_local > ns || h.n_bins > 0xFFFFFFFFull / SWG_BIN || h.n_local > h.n_total) {
+    // every count is checked against the size of the file before anything is sized by it
+    uint64_t file_bytes = 0;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long end = ftell(f);
+        if (end >= 0) file_bytes = (uint64_t)end;
+    }
+    const bool seek_ok = fseek(f, (long)sizeof h, SEEK_SET) == 0;
+    const uint64_t ns = h.n_bins <= 0xFFFFFFFFull / SWG_BIN ? h.n_bins * SWG_BIN : 0;
+    const bool counts_ok = seek_ok && h.n_bins <= 0xFFFFFFFFull / SWG_BIN && h.n_local <= ns && h.n_local <= h.n_total &&
+                           h.n_total < 0xFFFFFFF0ull && h.n_codes <= file_bytes && h.n_codes % 4 == 0 &&
+                           sizeof h + ns * 8 + h.n_codes == file_bytes;
+    if (!counts_ok) {
         fclose(f);
         return swg_set_global_error(SWG_ERR_IO, "swg_db_load: inconsistent header in %s", path);
     }
@@ -207,42 +242,50 @@ extern "C" int swg_db_load(const char *path, swg_db **out)
         fclose(f);
         return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_load: out of memory");
     }
-    bool ok = false;
-    try {
-        db->n_total = h.n_total;
-        db->n_local = h.n_local;
-        db->n_bins = (uint32_t)h.n_bins;
-        db->max_nblk = (uint32_t)h.max_nblk;
-        db->residues = h.residues;
-        db->rows_padded = h.rows_padded;
-        ok = get(f, db->bin_off, h.n_bins) && get(f, db->bin_nblk, h.n_bins) && get(f, db->order, ns) &&
-             get(f, db->lens, ns) && get(f, db->code_off, ns + 1) && get(f, db->codes, h.n_codes) &&
-             get(f, db->packed, h.n_packed);
-    } catch (const std::bad_alloc &) {
-        ok = false;
+    std::unique_ptr<swg_db> holder(db);
+    struct Closer {
+        FILE *f;
+        ~Closer() { fclose(f); }
+    } closer{f};
+    db->n_total = h.n_total;
+    db->n_bins = (uint32_t)h.n_bins;
+    bool ok = get(f, db->order, ns) && get(f, db->lens, ns);
+    // structural checks before the tables are derived: nothing read from the file is trusted as an
+    // index or a size unchecked, and the invariants the kernels rely on are verified, not assumed
+    // (lengths sorted longest first, so that a pair's second sequence is the shorter one; empty
+    // slots only at the end)
+    for (size_t s = 0; s < ns && ok; ++s) {
+        const bool empty = db->order[s] == 0xFFFFFFFFu;
+        ok = (empty || db->order[s] < db->n_total) && (!empty || db->lens[s] == 0) && db->lens[s] <= 0x3FFFFFFFu &&
+             (s == 0 || db->lens[s] <= db->lens[s - 1]) && (s == 0 || empty || db->order[s - 1] != 0xFFFFFFFFu);
     }
-    fclose(f);
-    // cheap structural checks: nothing read from the file is trusted as an index unchecked
     if (ok) {
-        uint64_t dwords = 0;
-        for (size_t b = 0; b < db->n_bins && ok; ++b) {
-            ok = db->bin_off[b] == dwords && db->bin_nblk[b] >= 1 && db->bin_nblk[b] <= db->max_nblk;
-            dwords += (uint64_t)db->bin_nblk[b] * SWG_BIN;
-        }
-        ok = ok && dwords == db->packed.size() && db->code_off[ns] == db->codes.size() &&
-             db->residues == db->codes.size() && db->rows_padded == dwords * SWG_ROWS_PER_BLK;
-        for (size_t s = 0; s < ns && ok; ++s) {
-            ok = db->code_off[s + 1] - db->code_off[s] == db->lens[s] &&
-                 (db->order[s] == 0xFFFFFFFFu || db->order[s] < db->n_total) &&
-                 db->lens[s] <= (uint64_t)db->bin_nblk[s / SWG_BIN] * SWG_ROWS_PER_BLK;
-        }
+        derive_tables(db);
+        ok = db->n_local == h.n_local && db->residues == h.residues && db->code_off.back() == h.n_codes &&
+             get(f, db->codes, h.n_codes);
     }
-    if (!ok) {
-        delete db;
-        return swg_set_global_error(SWG_ERR_IO, "swg_db_load: %s is truncated or corrupt", path);
+    if (ok) { // residue bytes: index << 3 of an index in 1..31, zeros up to the dword boundary
+        int bad = 0;
+        const long long nsl = (long long)ns;
+#pragma omp parallel for schedule(dynamic, 512) reduction(| : bad) num_threads(swg_host_threads())
+        for (long long s = 0; s < nsl; ++s) {
+            const uint8_t *cd = db->codes.data() + db->code_off[s];
+            const uint32_t len = db->lens[s];
+            for (uint32_t j = 0; j < len; ++j) bad |= (cd[j] & 7u) != 0 || cd[j] == 0;
+            for (uint32_t j = len; j < (len + 3) / 4 * 4; ++j) bad |= cd[j] != 0;
+        }
+        ok = bad == 0;
     }
-    *out = db;
+    if (!ok) return swg_set_global_error(SWG_ERR_IO, "swg_db_load: %s is truncated or corrupt", path);
+    *out = holder.release();
     return SWG_OK;
+}
+
+extern "C" int swg_db_load(const char *path, swg_db **out)
+{
+    if (!path || !out) return swg_set_global_error(SWG_ERR_ARG, "swg_db_load: NULL argument");
+    *out = nullptr;
+    return guarded("swg_db_load", [&] { return load_impl(path, out); });
 }
 
 extern "C" void swg_db_free(swg_db *db)
@@ -255,8 +298,12 @@ extern "C" void swg_db_free(swg_db *db)
 extern "C" size_t swg_db_count(const swg_db *db) { return db ? db->n_local : 0; }
 extern "C" size_t swg_db_total_count(const swg_db *db) { return db ? db->n_total : 0; }
 extern "C" uint64_t swg_db_residues(const swg_db *db) { return db ? db->residues : 0; }
+// what swg_db_upload copies to the GPU: the residue bytes and 16 bytes per slot (length, original
+// index, offset), plus one block offset per pair of sequences
 extern "C" uint64_t swg_db_packed_bytes(const swg_db *db)
 {
-    return db ? (uint64_t)db->packed.size() * 4u + (uint64_t)db->n_bins * 12u : 0;
+    if (!db) return 0;
+    const uint64_t ns = (uint64_t)db->n_bins * SWG_BIN;
+    return (uint64_t)db->codes.size() + ns * 16u + 8u + (ns / 2 + 1) * 4u;
 }
 extern "C" const uint32_t *swg_db_order(const swg_db *db) { return db ? db->order.data() : nullptr; }

@@ -8,27 +8,48 @@ import sys
 from conftest import ROOT
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_config2_bench.json")))
-    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
-                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
-                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
-        assert isinstance(d[k], t), k
-    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["unit"] == "GCUPS" and d["data"] == "synthetic" and d["dtype"] in ("int16", "int32")
-    assert "workload" in d["config"] and "model" not in d["config"]
-    r = d["roofline"]
+def _check_block(b, n_gpus=1):
+    r = b["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
     # achieved = algorithmic bytes of one launch / measured kernel time
     assert abs(r["achieved"] - r["bytes_alg_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] >= 0.5 * r["bytes_alg_per_launch"]
+    assert "workload" in b["config"] and "model" not in b["config"]
+    # value = cells of the WHOLE database * steps / elapsed: consistent with ms_per_step and the workload
+    cells = b["config"]["lq"] * b["config"]["residues_total"]
+    assert abs(b["value"] - cells / (b["ms_per_step"] * 1e-3) / 1e9) < 0.01 * b["value"]
+    assert b["unit"] == "GCUPS" and b["dtype"] in ("int16", "int32")
+    assert r["kernel_ms"] <= b["ms_per_step"] * 1.02
+    assert b.get("verify", {"ok": True})["ok"] is True
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The default one-GPU line: headline = config 3, one block per configuration 2, 3, 4 (share), 5, and
+    the whole 10M-sequence config 4 as the N = 1 point of the scaling curve."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("configs", dict)):
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["scaling"] == "strong" and d["higher_is_better"] is True
+    assert d["unit"] == "GCUPS" and d["data"] == "synthetic"
+    assert d["config"]["workload"].startswith("config 3:") and d["config"]["n_seqs"] == 570000
+    _check_block(d)
+    assert set(d["configs"]) == {"2", "3", "4", "5"}
+    for k, b in d["configs"].items():
+        assert b["config"]["workload"].startswith("config %s:" % k)
+        _check_block(b)
+    assert d["configs"]["3"]["value"] == d["value"]
+    ref = d["scaling_reference"]
+    assert ref["config"]["n_seqs"] == 10000000 and "ONE" in ref["config"]["workload"]
+    _check_block(ref)
     c = d["cpu_baseline"]
-    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("reference", "port")
-    # value = cells of all steps / elapsed: consistent with ms_per_step and the workload
-    cells = d["config"]["lq"] * d["config"]["residues_per_gpu"] * d["n_gpus"]
-    assert abs(d["value"] - cells / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    assert set(("value", "unit", "cores", "kind", "sample", "cpu_model", "one_thread_gcups")) <= set(c)
+    assert c["kind"] in ("reference", "port")
+    h = d["host_inclusive"]
+    assert h["upload_bytes"] < 1.1 * d["configs"]["2"]["config"]["residues_total"]     # about one byte per residue
 
 
 def test_bench_help_and_launch_rule_need_no_gpu():

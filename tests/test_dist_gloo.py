@@ -1,6 +1,7 @@
-"""CPU, world sizes 2 and 4 over gloo: the multi-GPU path of bench.py without GPUs.  Each rank packs
-its shard of one database (round-robin bins), scores it with the oracle (standing in for the
-GPU), and the ranks merge their top-K lists with the same single max-all-reduce bench.py uses."""
+"""CPU, world sizes 2 and 4 over gloo: the multi-GPU path of bench.py without GPUs.  Each rank
+generates and packs only its own bins of ONE global database (the sharded generator and
+swg_db_pack_shard: the partition code bench.py --gpus N runs), scores them with the oracle (standing
+in for the GPU), and the ranks merge their top-K lists with the same single max-all-reduce bench.py uses."""
 import os
 import sys
 
@@ -22,9 +23,19 @@ def _worker(rank, world, port, tmp, n_seqs):
     try:
         sc = swg.load_scoring("BLOSUM62")
         q = swg.synth_query(11, 64)
-        flat, off = swg.synth_db(11, n_seqs, max_len=200)
+        flat, off = swg.synth_db(11, n_seqs, max_len=200)          # the whole database: for the oracle only
         want = orc.score_db(q, flat, off, sc.table(), -2, -1)
-        shard = swg.Database(flat, off, rank, world)
+        # what bench.py --gpus N does on every rank: generate only this rank's bins of the one global
+        # database and pack them as a shard that was cut elsewhere
+        sh = swg.synth_db_shard(11, n_seqs, rank, world, max_len=200)
+        assert sh["residues_total"] == int(off[-1])
+        shard = swg.Database(sh["flat"], sh["offsets"], index=sh["index"], n_total=n_seqs)
+        cut = swg.Database(flat, off, rank, world)                 # the same shard cut from the whole
+        assert np.array_equal(shard.order(), cut.order()) and shard.residues == cut.residues
+        for i in range(0, len(sh["index"]), 97):                   # the residues are the global database's
+            g = int(sh["index"][i])
+            assert np.array_equal(sh["flat"][int(sh["offsets"][i]):int(sh["offsets"][i + 1])],
+                                  flat[int(off[g]):int(off[g + 1])])
         mine = shard.order()
         mine = mine[mine != 0xFFFFFFFF]                            # empty slots of the last bin
         assert len(mine) == shard.count

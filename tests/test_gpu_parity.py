@@ -661,3 +661,59 @@ def test_randomised_soak():
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.main(30.0, 11) == 0
+
+
+def _db_with_empties(swg, seed, n, n_empty, max_len):
+    """Random database with n_empty zero-length records mixed in at seeded positions."""
+    flat, off = swg.synth_db(seed, n, min_len=1, max_len=max_len)
+    lens = np.diff(off.astype(np.int64))
+    rng = np.random.default_rng(seed)
+    lens[rng.choice(n, size=n_empty, replace=False)] = 0
+    perm = rng.permutation(n)                              # and not in sorted order either
+    seqs = [flat[int(off[i]):int(off[i]) + int(lens[i])] for i in perm]
+    off2 = np.zeros(n + 1, dtype=np.uint64)
+    off2[1:] = np.cumsum([len(s) for s in seqs])
+    flat2 = np.concatenate(seqs) if int(off2[-1]) else np.zeros(0, np.int8)
+    return flat2, off2
+
+
+@pytest.mark.parametrize("n,n_empty,max_len", [(2000, 0, 700), (1999, 37, 300), (257, 200, 9), (5, 5, 5), (1, 0, 3)])
+def test_device_built_tokens_equal_the_host_builder(swg, ctx, n, n_empty, max_len):
+    """The pair tokens are built on the device from the uploaded residue bytes; the host restatement of
+    the same layout (swg_diag_host.cpp: write_pair_tokens) must give the same image bit for bit --
+    odd counts (a pair without a second sequence), empty sequences and empty pairs included."""
+    flat, off = _db_with_empties(swg, 1234 + n, n, n_empty, max_len)
+    db = swg.Database(flat, off).upload(ctx)
+    dev = db.debug_pair_tokens(ctx, from_host=False)
+    host = db.debug_pair_tokens(ctx, from_host=True)
+    assert dev.size == host.size and dev.size > 0
+    assert np.array_equal(dev, host), int(np.nonzero(dev != host)[0][0])
+    # every pair carries exactly one last-row flag: the tail lane pops one pair id per flag
+    rows = dev.view(np.uint16)
+    assert int(((rows & 2) != 0).sum()) == (db.count + 1) // 2
+    db.close()
+
+
+def test_empty_records_mixed_in(swg, ctx, orc):
+    """Zero-length records score 0 and must not disturb their neighbours' pair ids (an empty pair still
+    hands its id to the tail lane), in every engine and through the long class."""
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(5, 90)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    for seed, n, n_empty, max_len in ((1, 3000, 301, 400), (2, 700, 650, 40), (3, 130, 129, 2000)):
+        flat, off = _db_with_empties(swg, seed, n, n_empty, max_len)
+        want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+        assert (want[np.diff(off.astype(np.int64)) == 0] == 0).all()
+        db = swg.Database(flat, off).upload(ctx)
+        for opts in ({}, {"engine": 1}, {"work_queue": 0}, {"long_split": 64}, {"force_bits": 32},
+                     {"group_lanes": 64, "cols_per_wave": 2}):
+            _reset_options(ctx)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            got, hits, st = ctx.search(db, k=20)
+            assert np.array_equal(got, want), (seed, opts, st)
+            assert hits == orc.topk(want, 20)
+        db.close()
+    _reset_options(ctx)

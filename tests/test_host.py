@@ -186,10 +186,12 @@ def test_pack_orders_bins_and_validates(swg):
     for L in np.unique(sl):                              # stable among equal lengths
         o = order[sl == L]
         assert (np.diff(o) > 0).all()
-    # padded footprint: 128 slots x ceil(maxlen/4) dwords per bin
+    # what goes to the GPU: one byte per residue, every sequence a run of whole dwords, plus 16 bytes
+    # per slot (length, original index, offset) and one block offset per pair of sequences
     nb = (1000 + 127) // 128
-    expect = sum(((int(sl[b * 128]) + 3) // 4) * 128 * 4 for b in range(nb))
-    assert db.packed_bytes == expect + nb * 12
+    ns = nb * 128
+    expect = sum((int(l) + 3) // 4 * 4 for l in lens) + ns * 16 + 8 + (ns // 2 + 1) * 4
+    assert db.packed_bytes == expect
     # shards partition the bins round-robin
     seen = []
     for r in range(3):
@@ -209,6 +211,47 @@ def test_pack_orders_bins_and_validates(swg):
         swg.Database(flat, off, 3, 3)
     empty = swg.Database(np.zeros(0, np.int8), np.zeros(1, np.uint64))
     assert empty.count == 0
+    # n == 0 with NULL arrays is an empty database, not a crash (the C ABI is called directly)
+    import ctypes as C
+    h = C.c_void_p()
+    assert swg.lib.swg_db_pack(None, None, 0, 0, 1, C.byref(h)) == 0 and swg.lib.swg_db_count(h) == 0
+    swg.lib.swg_db_free(h)
+
+
+def test_presharded_pack_equals_sharding_the_whole(swg, tmp_path):
+    """A rank that generates only its own bins (swg_synth_db_shard) and packs them (swg_db_pack_shard) holds
+    byte for byte what swg_db_pack(whole database, rank, world) keeps -- the multi-GPU bench's path."""
+    n = 1000
+    q = swg.synth_query(21, 60)
+    for kw in (dict(), dict(query=q, fraction=0.05, subst=0.05)):
+        whole = swg.synth_db(21, n, max_len=400, **kw)
+        flat, off = whole[0], whole[1]
+        for world in (1, 2, 3, 8, 16):                    # 8 bins: 16 ranks leave half of them empty-handed
+            seen, residues = [], 0
+            for r in range(world):
+                sh = swg.synth_db_shard(21, n, r, world, max_len=400, **kw)
+                assert sh["n_total"] == n and sh["residues_total"] == int(off[-1])
+                if kw:
+                    assert sh["planted"] == whole[2]
+                # the shard's sequences are the whole database's, at their global indices
+                for i in (0, len(sh["index"]) // 2, len(sh["index"]) - 1):
+                    if len(sh["index"]):
+                        g = int(sh["index"][i])
+                        assert np.array_equal(sh["flat"][int(sh["offsets"][i]):int(sh["offsets"][i + 1])],
+                                              flat[int(off[g]):int(off[g + 1])])
+                a = swg.Database(flat, off, r, world)
+                b = swg.Database(sh["flat"], sh["offsets"], index=sh["index"], n_total=n)
+                assert (a.count, a.total_count, a.residues) == (b.count, b.total_count, b.residues)
+                assert np.array_equal(a.order(), b.order())
+                pa, pb = tmp_path / "a.swg", tmp_path / "b.swg"
+                a.save(str(pa))
+                b.save(str(pb))
+                assert pa.read_bytes() == pb.read_bytes()
+                seen += list(b.order())
+                residues += b.residues
+            assert sorted(seen) == list(range(n)) and residues == int(off[-1])
+    with pytest.raises(swg.SwgError):                     # an index outside the database is refused
+        swg.Database(flat[:int(off[2])], off[:3], index=np.array([0, n], np.uint32), n_total=n)
 
 
 def test_packed_database_file_roundtrip(swg, tmp_path):
@@ -221,12 +264,34 @@ def test_packed_database_file_roundtrip(swg, tmp_path):
            (db.count, db.total_count, db.residues, db.packed_bytes)
     assert np.array_equal(back.order(), db.order())
     raw = open(path, "rb").read()
-    for bad in (raw[:100], raw[:-7], b"NOTADB00" + raw[8:], raw[:40] + b"\xff" * 8 + raw[48:]):
+    ns = ((db.count + 127) // 128) * 128
+    hdr = 8 + 8 * 8
+    import struct
+
+    def patched(at, val, size=8):
+        return raw[:at] + struct.pack("<Q" if size == 8 else "<I", val) + raw[at + size:]
+
+    swapped = bytearray(raw)                              # two neighbouring lengths out of order
+    lens_at = hdr + ns * 4
+    fl = np.frombuffer(raw, dtype="<u4", count=ns, offset=lens_at)
+    i = int(np.nonzero(fl[:-1] > fl[1:])[0][0]) * 4 + lens_at
+    swapped[i:i + 4], swapped[i + 4:i + 8] = raw[i + 4:i + 8], raw[i:i + 4]
+    codes_at = hdr + ns * 8
+    cases = {
+        "truncated header": raw[:50], "truncated body": raw[:-7], "bad magic": b"NOTADB00" + raw[8:],
+        "n_bins huge": patched(24, 1 << 40), "n_codes huge": patched(40, 1 << 62), "n_total tiny": patched(8, 1),
+        "n_local lies": patched(16, db.count - 1), "residues lie": patched(32, db.residues + 1),
+        "order out of range": patched(hdr, 0x7FFFFFFF, 4), "lengths unsorted": bytes(swapped),
+        "residue byte with low bits": raw[:codes_at] + b"\x0b" + raw[codes_at + 1:],
+        "padding residue inside a sequence": raw[:codes_at] + b"\x00" + raw[codes_at + 1:],
+        "trailing junk": raw + b"\0" * 4,
+    }
+    for name, bad in cases.items():
         p2 = tmp_path / "bad.swgdb"
         p2.write_bytes(bad)
         with pytest.raises(swg.SwgError) as e:
             swg.Database(path=str(p2))
-        assert e.value.code == swg.SWG_ERR_IO
+        assert e.value.code == swg.SWG_ERR_IO, name
     with pytest.raises(swg.SwgError):
         swg.Database(path=str(tmp_path / "missing.swgdb"))
 
