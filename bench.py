@@ -279,8 +279,13 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
     block = None
     if env.rank == 0:
         gcups = cells_total * steps / elapsed / 1e9
-        k_ms = float(np.mean(fill_ms))
-        bytes_alg = int(last["bytes_alg"])
+        # a query of several passes is one launch of the fill kernel per pass: the roofline figures are per
+        # launch (what rocprofv3's per-kernel average and the PMC counters are), so the step's fill time
+        # and its algorithmic bytes are divided by the number of launches
+        launches = max(1, int(last["passes"])) if last["engine"] == 2 and last["path_bits"] == 16 and last["work_queue"] else 1
+        step_fill_ms = float(np.mean(fill_ms))
+        k_ms = step_fill_ms / launches
+        bytes_alg = int(last["bytes_alg"]) // launches
         achieved = bytes_alg / (k_ms * 1e-3) / 1e9
         traffic = None
         if os.path.exists(a.traffic_json):
@@ -296,7 +301,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
         # (tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt), the fill kernels get to 4.26.
         ops_per_cell = 5.0 if last["path_bits"] == 16 else 12.0
         simds = 256 * 4
-        kernel_gcups = cells_local / (k_ms * 1e-3) / 1e9
+        kernel_gcups = cells_local / (step_fill_ms * 1e-3) / 1e9
         peak_issue = simds * 64 / 4.0 * 2.4e9 / ops_per_cell / 1e9
         peak_microbench = simds * 64 / 4.56 * 2.35e9 / ops_per_cell / 1e9
         if last["engine"] == 2 and last["path_bits"] == 16:
@@ -332,6 +337,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
+                "launches_per_step": launches,
                 "binding_roof": {"bound": "valu_issue", "kernel_gcups": round(kernel_gcups, 2),
                                  "instr_per_cell": ops_per_cell,
                                  "cycles_per_wave_instr": 4.0, "clock_ghz": 2.4,
@@ -339,7 +345,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
                                  "frac_of_issue_peak": round(kernel_gcups / peak_issue, 4),
                                  "peak_gcups_microbenchmark": round(peak_microbench, 1)},
             },
-            "kernel_ms": {"fill": round(k_ms, 4), "search_total": round(float(np.mean(total_ms)), 4),
+            "kernel_ms": {"fill": round(step_fill_ms, 4), "search_total": round(float(np.mean(total_ms)), 4),
                           "rescore": round(float(last["rescore_ms"]), 4), "topk_host": round(float(last["topk_ms"]), 4)},
             "setup_s": {"generate": round(t_gen, 3), "pack": round(t_pack, 3)},
         }

@@ -815,8 +815,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     // wavefronts of a SIMD see the same phase) plus the rank, so that at any time they hold
     // different priorities: rotating on a private counter leaves ties, and ties go to the oldest.
     auto take_turn = [&]() {
-        const uint32_t phase = (uint32_t)(wall_clock64() >> SWG_DYN_TURN_SHIFT);
-        const uint32_t turn = (phase + rank) % p.turn_levels;
+        // (3 or 4 levels: a remainder by a run-time value would be a float-reciprocal sequence on the
+        // VALU every block; by the constant 3 it is one scalar multiply-high)
+        const uint32_t x = ((uint32_t)(wall_clock64() >> SWG_DYN_TURN_SHIFT) + rank) & 0xFFFFu;
+        const uint32_t turn = p.turn_levels == 4u ? (x & 3u) : x - 3u * ((x * 0xAAABu) >> 17);
         if (turn == 0u) __builtin_amdgcn_s_setprio(0);
         else if (turn == 1u) __builtin_amdgcn_s_setprio(1);
         else if (turn == 2u) __builtin_amdgcn_s_setprio(2);

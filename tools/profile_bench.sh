@@ -1,11 +1,13 @@
-# rocprofv3 evidence for bench.py's default command (config 2, 1 GPU): kernel trace + stats,
-# then HBM counters in their own passes (MI355X_MICROARCH.md, HBM / rocprofv3 PMC sections).
-CFG=${1:-2}
+# rocprofv3 evidence for one configuration of bench.py (1 GPU): kernel trace + stats, then HBM
+# counters in their own passes (MI355X_MICROARCH.md, HBM / rocprofv3 PMC sections), then SQ / LDS counters.
+#   bash tools/profile_bench.sh <config> [steps]      -> gpurun_out/prof_c<config>/{summary,traffic}.json
+CFG=${1:-3}
+STEPS=${2:-${STEPS:-20}}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_c$CFG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--config $CFG --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline --no-host-inclusive"
+ARGS="--config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-host-inclusive --no-verify"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
