@@ -426,7 +426,7 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
 static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom, int k_real = 1,
                                int k_padded = 1)
 {
-    const int chunk_cols = which == 2 ? 2 : 4; // [3]: 4-column chunks inside per-lane slices
+    const int chunk_cols = 4;
     const size_t bytes = (size_t)ncols * 32 * elem_size;
     const uint64_t tag = (ctx->epoch << 32) ^ geom;
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
@@ -472,7 +472,7 @@ static int ensure_diag_layout(swg_ctx *ctx, swg_db *db, int cls, const SwgDiagPl
             return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "diagonal layout: out of host memory");
         }
         const size_t S = L.n_streams;
-        HIP_TRY(ctx, hipMalloc(&L.d_tok, std::max<size_t>(8, L.tok.size() * 4)));
+        HIP_TRY(ctx, hipMalloc(&L.d_tok, std::max<size_t>(16, L.tok.size() * 4)));
         HIP_TRY(ctx, hipMalloc(&L.d_stream_off, (S + 1) * 8));
         HIP_TRY(ctx, hipMalloc(&L.d_stream_pairs, std::max<size_t>(4, L.stream_pairs.size() * 4)));
         HIP_TRY(ctx, hipMalloc(&L.d_stream_pair_off, (S + 1) * 4));
@@ -512,7 +512,7 @@ static int ensure_pair_tokens(swg_ctx *ctx, swg_db *db)
     }
     T.total_blocks = T.pair_blocks_prefix.back();
     const uint32_t n_pairs = (uint32_t)(T.pair_blocks_prefix.size() - 1);
-    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(8, (size_t)T.total_blocks * 8)));
+    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(16, (size_t)T.total_blocks * 16)));
     HIP_TRY(ctx, hipMalloc(&T.d_pair_off, T.pair_blocks_prefix.size() * 4));
     // (the host vector lives as long as the database: no wait needed for the copy)
     HIP_TRY(ctx, hipMemcpyAsync(T.d_pair_off, T.pair_blocks_prefix.data(), T.pair_blocks_prefix.size() * 4,
@@ -551,7 +551,7 @@ extern "C" int swg_debug_pair_tokens(swg_ctx *ctx, swg_db *db, int from_host, ui
     const int rc = ensure_pair_tokens(ctx, db);
     if (rc != SWG_OK) return rc;
     if (!db->ptok.ok) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_debug_pair_tokens: database too large for pair tokens");
-    const size_t n = (size_t)db->ptok.total_blocks * 2;
+    const size_t n = (size_t)db->ptok.total_blocks * 4;
     *n_dwords = n;
     if (out && n <= cap_dwords && n) {
         HIP_TRY(ctx, hipMemcpyAsync(out, db->ptok.d_tok, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -617,12 +617,15 @@ static int ensure_scratch(swg_ctx *ctx, size_t dwords)
 // ---------------------------------------------------------------------------
 // diagonal engine: make a work plan resident, launch it
 // ---------------------------------------------------------------------------
-static int diag_profile_slot(const SwgDiagPlan &pl) { return pl.K % 2 ? 3 : pl.K % 4 == 0 ? 0 : 2; }
+// Which profile buffer a class reads: [0] the plain [col/4][32][4] layout, which every geometry with
+// whole chunks per lane (K % 4 == 0) slices the same way; a K that is not a multiple of 4 pads every
+// lane's slice to whole chunks, a layout of its own: [3] for the bulk, [2] for the long class.
+static int diag_profile_slot(const SwgDiagPlan &pl, int cls) { return pl.K % 4 == 0 ? 0 : cls == 0 ? 3 : 2; }
 
 static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
 {
     uint32_t ncols[4] = {0, 0, 0, 0};
-    int odd_k = 0;
+    int own_k[4] = {0, 0, 0, 0};
     if (ctx->opt_dynamic) {
         int rc = ensure_pair_tokens(ctx, db);
         if (rc != SWG_OK) return rc;
@@ -636,16 +639,15 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
             HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[0], bytes));
             HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[1], bytes));
         }
-        const int slot = diag_profile_slot(wk.plan[c]);
+        const int slot = diag_profile_slot(wk.plan[c], c);
         ncols[slot] = std::max<uint32_t>(ncols[slot], (uint32_t)(wk.plan[c].npass * wk.plan[c].G *
                                                                  swg_diag_padded_cols(wk.plan[c].K)));
-        if (slot == 3) odd_k = wk.plan[c].K; // (the planner gives the long class an even K)
+        if (slot != 0) own_k[slot] = wk.plan[c].K;
     }
-    // classes with the same chunking slice the same [col/ch][32][ch] profile
     for (int slot = 0; slot < 4; ++slot)
         if (slot != 1 && ncols[slot]) {
-            int rc = slot == 3 ? ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ((uint64_t)odd_k << 24) ^ ncols[slot],
-                                                     odd_k, swg_diag_padded_cols(odd_k))
+            int rc = slot != 0 ? ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ((uint64_t)own_k[slot] << 24) ^ ncols[slot],
+                                                     own_k[slot], swg_diag_padded_cols(own_k[slot]))
                                : ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ncols[slot]);
             if (rc != SWG_OK) return rc;
         }
@@ -687,7 +689,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.q_begin = (uint32_t)wk.pair_begin[c];
             q.q_end = (uint32_t)wk.pair_end[c];
             q.queue = db->d_counters + SWG_QUEUE_WORD(c); // zeroed with the other counters before the fill
-            q.profile = ctx->d_profile[diag_profile_slot(pl)];
+            q.profile = ctx->d_profile[diag_profile_slot(pl, c)];
             q.scores = db->d_scores;
             q.pair_limit = (uint32_t)(((size_t)db->n_bins * SWG_BIN) / 2);
             q.G = (uint32_t)pl.G;
@@ -719,7 +721,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                 // one launch per pass: the kernel boundary is what lets any lane group take any pair
                 if (pass > 0)
                     HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, qs));
-                q.profile = ctx->d_profile[diag_profile_slot(pl)] + (size_t)pass * slice;
+                q.profile = ctx->d_profile[diag_profile_slot(pl, c)] + (size_t)pass * slice;
                 q.edge_in = pass > 0 ? T.d_edge[(pass - 1) & 1] : nullptr;
                 q.edge_out = pass + 1 < pl.npass ? T.d_edge[pass & 1] : nullptr;
                 HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pl.wide != 0, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
@@ -733,7 +735,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
         d.stream_pairs = L.d_stream_pairs;
         d.stream_pair_off = L.d_stream_pair_off;
         d.n_streams = L.n_streams;
-        d.profile = ctx->d_profile[diag_profile_slot(pl)];
+        d.profile = ctx->d_profile[diag_profile_slot(pl, c)];
         d.scores = db->d_scores;
         d.scratch = L.d_scratch;
         d.npass = (uint32_t)pl.npass;

@@ -80,7 +80,6 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
         for (int gi = 0; gi < 2; ++gi) {
             const int G = groups[gi];
             if (g_swg_long_group > 0 && G != (int)g_swg_long_group) continue;
-            if (info.K % 2) continue; // the long class shares the profile buffers with the bulk: even K only
             const size_t cols = (size_t)G * info.K;
             if ((size_t)G * swg_diag_padded_cols(info.K) * 64 > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
@@ -155,7 +154,9 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     }
                     if (!improves) continue;
                 }
-                const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)));
+                // (the work-queue kernels keep a 512-byte record per lane group behind the profile)
+                const size_t lds_wg = dynamic ? swg_diag_dyn_lds_bytes(info.K, G, W) : lds;
+                const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds_wg)));
                 const int eff_wps = std::min(4, wps * per_cu);
                 const double cps = kCyclesPerInstr[eff_wps];
                 const uint64_t spw = (uint64_t)W * NG;
@@ -278,8 +279,13 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
 }
 
 // Tokens of one pair of sequences (two reset rows, then one row per residue of the longer
-// one, the last block filled up with padding rows); returns the number of 4-row blocks.
-static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint16_t *t)
+// one, the last block filled up with padding rows), one 32-bit token per row: byte 0 = X residue
+// byte, byte 1 = Y residue byte, bit 16 = reset row, bit 17 = last row; returns the number of 4-row
+// blocks.  The device builds the same image from the resident residue bytes
+// (swg_build_tokens_kernel); this is its host restatement, used by the fixed-stream layout and by
+// the tests that compare the two.
+static const uint32_t kTokReset = 0x10000u, kTokLast = 0x20000u;
+static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint32_t *t)
 {
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     const uint32_t lx = db->lens[2 * p];
@@ -287,17 +293,17 @@ static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint16_t *t)
     const uint32_t ly = has_y ? db->lens[2 * p + 1] : 0;
     const uint8_t *cx = db->codes.data() + db->code_off[2 * p];
     const uint8_t *cy = has_y ? db->codes.data() + db->code_off[2 * p + 1] : nullptr;
-    t[0] = 1; // reset rows: flag bit0, padding residue for both sequences
-    t[1] = 1;
-    uint16_t *r = t + 2;
+    t[0] = kTokReset; // reset rows: padding residue for both sequences
+    t[1] = kTokReset;
+    uint32_t *r = t + 2;
     const uint32_t both = std::min(lx, ly); // (= ly: sorted order)
-    for (uint32_t j = 0; j < both; ++j) r[j] = (uint16_t)(cx[j] | (uint32_t)cy[j] << 8);
+    for (uint32_t j = 0; j < both; ++j) r[j] = (uint32_t)cx[j] | (uint32_t)cy[j] << 8;
     for (uint32_t j = both; j < lx; ++j) r[j] = cx[j];
     const uint64_t blocks = (2ull + lx + 3) / 4;
     for (uint64_t j = 2ull + lx; j < blocks * 4; ++j) t[j] = 0; // rest of the last block: padding rows
     // last row of the pair: X's last residue; for an empty pair the second reset row, so that every
-    // pair hands its id to the tail lane exactly once
-    t[lx + 1] |= 2u;
+    // pair is finished by the tail lane exactly once
+    t[lx + 1] |= kTokLast;
     return blocks;
 }
 
@@ -358,11 +364,11 @@ void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_
     uint64_t rows_total = 0;
     for (size_t p = pair_begin; p < pair_end; ++p) rows_total += 2ull + db->lens[2 * p];
     L->pair_rows_total = rows_total;
-    L->tok.assign(L->total_blocks * 2, 0u);
-    uint16_t *base = reinterpret_cast<uint16_t *>(L->tok.data()); // one 16-bit token per row
+    L->tok.assign(L->total_blocks * 4, 0u);
+    uint32_t *base = L->tok.data(); // one 32-bit token per row
 #pragma omp parallel for schedule(dynamic, 16) num_threads(swg_host_threads())
     for (long long s = 0; s < (long long)n_streams; ++s) {
-        uint16_t *t = base + L->stream_off[s] * 4;
+        uint32_t *t = base + L->stream_off[s] * 4;
         for (uint32_t i = L->stream_pair_off[s]; i < L->stream_pair_off[s + 1]; ++i)
             t += write_pair_tokens(db, L->stream_pairs[i], t) * 4; // rest of the last block stays padding
     }
@@ -384,9 +390,9 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
     if (!tok) return 0; // offsets only: the tokens themselves are built on the device
     // every pair writes all rows of its blocks, so the buffer needs no zero fill: its pages are
     // first touched by the threads that fill them
-    tok->reset(new uint32_t[std::max<size_t>(2, (size_t)total * 2)]);
-    *tok_dwords = (size_t)total * 2;
-    uint16_t *base = reinterpret_cast<uint16_t *>(tok->get());
+    tok->reset(new uint32_t[std::max<size_t>(4, (size_t)total * 4)]);
+    *tok_dwords = (size_t)total * 4;
+    uint32_t *base = tok->get();
 #pragma omp parallel for schedule(dynamic, 64) num_threads(swg_host_threads())
     for (long long p = 0; p < (long long)n_pairs; ++p)
         write_pair_tokens(db, (size_t)p, base + (size_t)(*pair_off)[p] * 4);

@@ -41,9 +41,9 @@ struct SwgDiagLayout {
     std::vector<uint64_t> stream_off;      // [n_streams+1]
     std::vector<uint32_t> stream_pairs;    // pair ids, stream-major
     std::vector<uint32_t> stream_pair_off; // [n_streams+1]
-    std::vector<uint32_t> tok;             // 2 dwords per block
+    std::vector<uint32_t> tok;             // 4 dwords per block (one 32-bit token per row)
     // device image
-    uint2 *d_tok = nullptr;
+    uint4 *d_tok = nullptr;
     uint64_t *d_stream_off = nullptr;
     uint32_t *d_stream_pairs = nullptr;
     uint32_t *d_stream_pair_off = nullptr;
@@ -64,7 +64,7 @@ struct SwgPairTokens {
     bool tried = false, ok = false;
     bool host_built = false; // diagnostics: tokens came from the host builder (option "host_tokens")
     uint64_t total_blocks = 0;
-    uint2 *d_tok = nullptr;
+    uint4 *d_tok = nullptr;
     uint32_t *d_pair_off = nullptr;
     uint2 *d_edge[2] = {nullptr, nullptr};    // multi-pass: (M,B) per row between consecutive passes, ping-pong
     std::vector<uint32_t> pair_blocks_prefix; // host copy of pair_off

@@ -37,12 +37,12 @@ struct SwgFillParams {
 
 // Diagonal engine (swg_diag_kernel): streams of sequence pairs, one per lane group.
 struct SwgDiagParams {
-    const uint2 *tok;                // stream-major token blocks (4 rows = 8 bytes each)
+    const uint4 *tok;                // stream-major token blocks (4 rows, one 32-bit token each)
     const uint64_t *stream_off;      // [n_streams+1] block offset of each stream
     const uint32_t *stream_pairs;    // pair ids in stream order
     const uint32_t *stream_pair_off; // [n_streams+1]
     uint32_t n_streams;
-    const uint8_t *profile;          // [npass][G*K/4][32][4] int16
+    const uint8_t *profile;          // [npass][G lanes][KP/4 chunks][32][4] int16
     int32_t *scores;                 // by sorted rank: pair p -> 2p, 2p+1
     uint2 *scratch;                  // multi-pass spill, one (M,B) per stream row
     uint32_t npass, G;
@@ -56,13 +56,13 @@ struct SwgDiagParams {
 #define SWG_DYN_SHARD_STRIDE 32u // dwords between counters: one 128-byte line each
 #define SWG_DYN_SIMD_SLOTS 8192u // wavefront-rank counters, one per physical SIMD (xcc, se, sh, cu, simd)
 struct SwgDiagDynParams {
-    const uint2 *tok;         // pair-major token blocks (4 rows = 8 bytes each), longest pair first
+    const uint4 *tok;         // pair-major token blocks (4 rows, one 32-bit token each), longest pair first
     const uint32_t *pair_off; // [n_pairs+1] block offset of each pair's tokens
     uint32_t q_begin, q_end;  // this launch serves pairs [q_begin, q_end) ...
     uint32_t *queue;          // ... handed out by these SWG_DYN_SHARDS counters (zero before the launch)
     uint32_t q2_begin, q2_end; // then helps with [q2_begin, q2_end) (empty: none), which another
     uint32_t *queue2;          // launch is serving off these counters
-    const uint8_t *profile;   // [G*K/ch][32][ch] int16
+    const uint8_t *profile;   // [G lanes][KP/4 chunks][32][4] int16
     int32_t *scores;          // by sorted rank: pair p -> 2p, 2p+1
     uint32_t pair_limit;      // pairs the score array has room for: nothing is written beyond it
     uint32_t G;
@@ -119,7 +119,7 @@ int swg_diag_padded_cols(int K); // layout columns of a lane's slice
 // Per-database layouts from the uploaded residue dwords (d_code_off in dwords): the pair-major
 // token array of the diagonal engine, and the bin image of the systolic engine / int32 kernels.
 hipError_t swg_launch_build_tokens(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
-                                   const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint2 *d_tok,
+                                   const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint4 *d_tok,
                                    hipStream_t stream);
 hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
                                  const uint64_t *d_bin_off, const uint32_t *d_bin_nblk, uint32_t n_bins,

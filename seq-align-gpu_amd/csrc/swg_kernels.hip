@@ -409,9 +409,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 // owns ONE pair of database sequences; lane g of the group holds K query columns
 // [g*K, (g+1)*K) and works on database row (t - g) at step t, so the group sweeps
 // the DP matrix as an anti-diagonal wavefront.  What crosses a lane boundary per
-// step -- the strip's right edge (M, B), the residue token and the running
-// maximum -- moves with DPP lane shifts (row_shr:1 inside a 16-lane row,
-// wave_shr:1 across the wavefront); nothing goes through LDS or memory.
+// step -- the strip's right edge (M, B) and the row's token -- moves with DPP lane
+// shifts (row_shr:1 inside a 16-lane row, wave_shr:1 across the wavefront);
+// nothing goes through LDS or memory.
 //
 // Why it exists next to the systolic kernel: there a lane walks K=32 columns of
 // 128 lock-stepped sequences, so a bin of long sequences is a serial chain of
@@ -420,12 +420,17 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 // sequences instead of 128, and sequences stream through a lane group back to
 // back (two all-padding "reset" rows between pairs clear the carried state), so
 // there is no pipeline fill per sequence and no padding to a bin's longest
-// member.  Streams of pairs are balanced on the host (longest first).
+// member.
 //
-// Token per database row: byte 0 = X residue (index<<3) | flags, byte 1 = Y
-// residue (index<<3); flags bit0 = reset row, bit1 = last row of the pair.
-#define SWG_TOK_RESET 1u
-#define SWG_TOK_LAST 2u
+// Token per database row, 32 bits: byte 0 = X residue (index<<3), byte 1 = Y residue
+// (index<<3), bit 16 = reset row, bit 17 = last row of the pair.  The residue bytes are the
+// LDS byte offsets of their profile rows as they stand (one SDWA add each forms the address),
+// a row with a flag is any token above 0xFFFF (one compare), and a 4-row block is one uint4
+// whose components are the rows (nothing to extract).  Costs 4 bytes per pair-row of HBM
+// instead of 2 -- irrelevant at 0.2 % of the HBM roofline -- and saves five VALU instructions
+// per lane-row.
+#define SWG_TOK_RESET 0x10000u
+#define SWG_TOK_LAST 0x20000u
 #define DPP_ROW_SHR1 0x111
 #define DPP_WAVE_SHR1 0x138
 
@@ -438,12 +443,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 template <int K, bool WIDE = false> struct CellsDiag {
     static constexpr uint32_t ZERO = WIDE ? 0x80008000u : 0u;
     DEVINL static uint32_t sub(uint32_t a, uint32_t b) { return WIDE ? pk_sub_i16_sat(a, b) : pk_sub_u16_sat(a, b); }
-    // columns per profile chunk: 4 (one ds_read_b64 per sequence), or 2 (ds_read_b32) when
-    // K = 2 mod 4; a chunk is [32 residues][CH] int16.  An odd K takes 4-column chunks and leaves
-    // the rest of its last chunk unused: a lane's slice of the profile is KP = K rounded up columns
-    // wide, the columns it works on are the first K (any K: G*K lands within G/2 columns of the
-    // query length on average instead of G).
-    static constexpr int CH = (K % 4 == 2) ? 2 : 4;
+    // A profile chunk is [32 residues][4 columns] int16 = 256 bytes; a lane's slice of the profile
+    // is KP = K rounded up to whole chunks, the columns it works on are the first K (any K: G*K
+    // lands within G/2 columns of the query length on average instead of 2*G).
+    static constexpr int CH = 4;
     static constexpr int KP = (K + CH - 1) / CH * CH;
     static constexpr int CHUNK = 32 * CH * 2;
     uint32_t M[K], G[K], A[K];
@@ -470,51 +473,35 @@ template <int K, bool WIDE = false> struct CellsDiag {
         mdl = (mdl & ~fm) | (ZERO & fm);
     }
 
-    // raw profile words of chunk c for both sequences (one LDS read each)
-    struct Raw {
-        uint32_t x[CH / 2], y[CH / 2];
-    };
-    DEVINL Raw load_chunk(const uint8_t *prof, uint32_t offx, uint32_t offy, int c) const
-    {
-        Raw r;
-        if constexpr (CH == 4) {
-            const uint2 wx = *reinterpret_cast<const uint2 *>(prof + offx + c * CHUNK);
-            const uint2 wy = *reinterpret_cast<const uint2 *>(prof + offy + c * CHUNK);
-            r.x[0] = wx.x, r.x[1] = wx.y, r.y[0] = wy.x, r.y[1] = wy.y;
-        } else {
-            r.x[0] = *reinterpret_cast<const uint32_t *>(prof + offx + c * CHUNK);
-            r.y[0] = *reinterpret_cast<const uint32_t *>(prof + offy + c * CHUNK);
-        }
-        return r;
-    }
-
-    // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows).  FENCED: software
+    // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows).  ax / ay: LDS byte
+    // address of the row's residue in this lane's first chunk, for sequence X / Y.  FENCED: software
     // pipeline with a depth of one chunk -- chunk c+1's profile reads are issued before chunk c's
     // arithmetic and nothing moves across the chunk boundary, so at most two chunks' words (8
     // registers) are in flight.  Left alone the scheduler hoists eight reads and K=24 spills.
     template <bool FENCED = false>
-    DEVINL uint2 row(const uint8_t *prof, uint32_t offx, uint32_t offy, uint32_t em, uint32_t eb,
-                     uint32_t go, uint32_t ge)
+    DEVINL uint2 row(const uint8_t *prof, uint32_t ax, uint32_t ay, uint32_t em, uint32_t eb, uint32_t go, uint32_t ge)
     {
         constexpr int NCH = KP / CH;
         uint32_t md = mdl;
         uint32_t gl = sub(em, go);
         uint32_t bl = eb;
-        Raw nextw = load_chunk(prof, offx, offy, 0);
+        uint2 nx = *reinterpret_cast<const uint2 *>(prof + ax), ny = *reinterpret_cast<const uint2 *>(prof + ay);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const Raw w = nextw;
-            if (c + 1 < NCH) nextw = load_chunk(prof, offx, offy, c + 1);
-            uint32_t s[CH];
-#pragma unroll
-            for (int h = 0; h < CH / 2; ++h) {
-                s[2 * h] = __builtin_amdgcn_perm(w.y[h], w.x[h], 0x05040100u);
-                s[2 * h + 1] = __builtin_amdgcn_perm(w.y[h], w.x[h], 0x07060302u);
+            const uint2 wx = nx, wy = ny;
+            if (c + 1 < NCH) {
+                nx = *reinterpret_cast<const uint2 *>(prof + ax + (c + 1) * CHUNK);
+                ny = *reinterpret_cast<const uint2 *>(prof + ay + (c + 1) * CHUNK);
             }
+            uint32_t s[CH];
+            s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
+            s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
+            s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
+            s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int k = CH * c + u;
-                if (k >= K) break; // unused tail of an odd K's last chunk
+                if (k >= K) break; // unused tail of the last chunk
                 const uint32_t t = pk_add_i16_sat(md, s[u]);
                 md = M[k];
                 const uint32_t a = pk_max_i16(G[k], sub(A[k], ge));
@@ -545,6 +532,18 @@ template <int CTRL> DEVINL uint32_t dpp_keep(uint32_t keep, uint32_t src)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)keep, (int)src, CTRL, 0xf, 0xf, false);
 }
 
+// row r of a 4-row token block (r is a constant after unrolling)
+DEVINL uint32_t block_row(const uint4 &b, int r) { return r == 0 ? b.x : r == 1 ? b.y : r == 2 ? b.z : b.w; }
+
+// A wave-uniform integer the optimizer cannot see through: a test on it stays one scalar compare
+// per use.  (A uniform bool that lives across the row loop is kept as a lane mask and turned back
+// into a condition with v_cndmask + v_cmp on every row.)
+DEVINL int opaque_uniform(int v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 template <int K, int MAXW, bool MULTIPASS, bool WIDE = false>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams p)
 {
@@ -568,10 +567,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
     const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
     if (wave_nblk >= p.prio_blocks) __builtin_amdgcn_s_setprio(3);
     const uint32_t rows = nblk * 4u;
-    const uint2 *tp = p.tok + boff;
+    const uint4 *tp = p.tok + boff;
     uint2 *sp = p.scratch + boff * 4u;
-    constexpr int CH = CellsDiag<K>::CH;
-    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / CH) * CellsDiag<K>::CHUNK;
+    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / 4) * CellsDiag<K>::CHUNK;
     const uint32_t slice = (uint32_t)G * CellsDiag<K>::KP * 64u;
     const int npass = MULTIPASS ? (int)p.npass : 1;
 
@@ -588,11 +586,12 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
         __syncthreads();
 
         constexpr uint32_t Z = CellsDiag<K, WIDE>::ZERO; // score 0 in the cells' representation
+        const uint4 none = make_uint4(0u, 0u, 0u, 0u);
         CellsDiag<K, WIDE> cells;
         cells.reset();
         uint32_t tok = 0u, m_out = Z, b_out = Z, c_out = Z, done = 0u;
-        uint2 cur = (leader && nblk > 0u) ? tp[0] : make_uint2(0u, 0u);
-        uint2 nxt = (leader && nblk > 1u) ? tp[1] : make_uint2(0u, 0u);
+        uint4 cur = (leader && nblk > 0u) ? tp[0] : none;
+        uint4 nxt = (leader && nblk > 1u) ? tp[1] : none;
         uint2 spc[4], spn[4];
         if (MULTIPASS) {
 #pragma unroll
@@ -605,8 +604,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
         for (uint32_t s4 = 0; s4 < nsteps; s4 += 4u) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t word = (r & 2) ? cur.y : cur.x;
-                const uint32_t fresh = (r & 1) ? (word >> 16) : (word & 0xFFFFu);
+                const uint32_t fresh = block_row(cur, r);
                 const uint32_t lm = MULTIPASS ? spc[r].x : Z, lb = MULTIPASS ? spc[r].y : Z;
                 uint32_t em, eb, cin;
                 if (G == 16) {
@@ -631,16 +629,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                         cin = t3;
                     }
                 }
-                // residue byte = index<<3 = byte offset of its row in a 4-column chunk (halved for 2)
-                const uint32_t ox = CH == 4 ? (tok & 0xF8u) : ((tok >> 1) & 0x7Cu);
-                const uint32_t oy = CH == 4 ? ((tok >> 8) & 0xF8u) : ((tok >> 9) & 0x7Cu);
                 // reset / last rows are rare: one wave-uniform test keeps their bookkeeping out of
                 // the common step (the recurrence itself is issued once, with per-lane gap operands)
-                const bool special = __builtin_amdgcn_ballot_w64((tok & (SWG_TOK_RESET | SWG_TOK_LAST)) != 0u) != 0ull;
+                const bool special = __builtin_amdgcn_ballot_w64(tok > 0xFFFFu) != 0ull;
                 uint32_t go_t = p.go, ge_t = p.ge;
                 if (special) {
                     // reset rows: gap magnitudes of all ones wipe A/G/B, two such rows wipe M
-                    const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
+                    const uint32_t fm = 0u - ((tok >> 16) & 1u);
                     if (WIDE) {
                         cells.wipe(fm);
                     } else {
@@ -649,7 +644,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                         ge_t |= fm;
                     }
                 }
-                const uint2 e = cells.template row<(K > 16)>(smem, base + ox, base + oy, em, eb, go_t, ge_t);
+                const uint2 e = cells.template row<(K > 16)>(smem, base + (tok & 0xFFu), base + ((tok >> 8) & 0xFFu), em,
+                                                              eb, go_t, ge_t);
                 c_out = pk_max_i16(cin, cells.best);
                 if (special && tail && (tok & SWG_TOK_LAST)) {
                     const uint32_t pr = p.stream_pairs[pair0 + done];
@@ -666,7 +662,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
             }
             const uint32_t bi = s4 / 4u + 2u;
             cur = nxt;
-            nxt = (leader && bi < nblk) ? tp[bi] : make_uint2(0u, 0u);
+            nxt = (leader && bi < nblk) ? tp[bi] : none;
             if (MULTIPASS) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -687,7 +683,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 }
 
 // ---------------------------------------------------------------------------
-// The diagonal fill with a work queue (single pass: the query fits G*K columns)
+// The diagonal fill with a work queue (one launch per pass of the query)
 // ---------------------------------------------------------------------------
 // Same lanes, same step, but a lane group is not handed a fixed stream of pairs:
 // its leader lane takes the next pair off a device-wide counter when the one it
@@ -699,29 +695,34 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 // issue port.  With the queue every resident wavefront stays busy until the
 // pairs are gone, whatever rate it ran at.
 //
-// A lane group's bookkeeping lives in LDS (64 dwords per group, after the
-// profile) and is only touched when one of the wavefront's pairs runs out; between
+// A lane group's bookkeeping lives in LDS (128 dwords per group, after the
+// profile) and is only touched when one of the wavefront's pairs begins or ends; between
 // such events a block costs a scalar compare and the leader's token load.  The
-// register file holds the DP state and one token index, which is what lets K=24
-// fit 128 VGPRs without spilling.  When a pair runs out its leader takes the next
-// one there and then (counter, then the pair's token range: two round trips, at
-// raised priority so that a wavefront whose turn it is to yield does not crawl
-// through the bookkeeping); that stalls one wavefront for a few microseconds
+// register file holds the DP state and one token index.  When a pair runs out its
+// leader takes the next one there and then (counter, then the pair's token range: two
+// round trips, at raised priority so that a wavefront whose turn it is to yield does not
+// crawl through the bookkeeping); that stalls one wavefront for a few microseconds
 // about once per hundred blocks while the others keep the issue port busy.
-// Pair ids reach the tail lane, which writes the scores, through a ring in the
-// same LDS record.  A launch may name a second range of pairs to go on with when
-// its own is empty: the long class ends early and then helps with the bulk.
+//
+// A pair's two scores: every lane keeps the maximum of its own columns over the pair's rows and,
+// on the pair's last row, joins it to the pair's slot of the record with two LDS atomic maxima;
+// the tail lane -- the last of the group to see that row -- then reads the slot, writes the two
+// scores and clears it.  (Carrying a running maximum from lane to lane instead costs a DPP move
+// and a packed max on EVERY row.)  Pair ids reach the tail lane through a ring in the same record;
+// a lane finds both by counting the last rows it has seen.  A launch may name a second range of
+// pairs to go on with when its own is empty: the long class ends early and then helps with the bulk.
 //
 // LDS record of a lane group: [0] value of the wavefront's block counter at which
 // the current pair has no more tokens to load (NONE: no pair and none to come),
-// [1] flags, [2] ids pushed, [3] ids popped, [32..63] ring of pair ids.
+// [1] flags, [2] ids pushed, [32..63] ring of pair ids, [64..127] ring of score pairs.
 #ifndef SWG_DYN_FENCE_ABOVE
 #define SWG_DYN_FENCE_ABOVE 16 // fence the profile prefetch for K above this
 #endif
-#define SWG_DYN_STATE 64u
+#define SWG_DYN_STATE 128u
 // Pairs between the leader (which is up to two token blocks ahead) and the tail lane: at most
 // (2*4 + 63) rows / 4 rows per shortest pair = 18 with 64 lanes per pair.
 #define SWG_DYN_RING 32u
+#define SWG_DYN_MAXES 64u
 #ifndef SWG_DYN_TURN_SHIFT
 #define SWG_DYN_TURN_SHIFT 14 // a turn lasts 2^14 ticks of the 100 MHz clock (164 us): long against a block even for the wavefront whose turn it is to yield
 #endif
@@ -767,9 +768,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     const int gshift = G == 16 ? 4 : G == 32 ? 5 : 6;
     const int g = lane & (G - 1);
     const bool leader = g == 0, tail = g == G - 1;
-    constexpr int CH = CellsDiag<K>::CH;
     constexpr uint32_t Z = CellsDiag<K, WIDE>::ZERO; // score 0 in the cells' representation
-    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / CH) * CellsDiag<K>::CHUNK;
+    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / 4) * CellsDiag<K>::CHUNK;
     const uint32_t slice = (uint32_t)G * CellsDiag<K>::KP * 64u;
     // recomputed where it is needed (rarely) instead of living in a register
     auto record = [&]() -> uint32_t * {
@@ -779,13 +779,20 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
     for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
         *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(p.profile + o);
-    if (g < 4) record()[g] = 0u; // every group is due at block 0
+    {
+        uint32_t *st = record();
+        if (g < 4) st[g] = 0u; // every group is due at block 0
+        for (uint32_t i = (uint32_t)g; i < 2u * SWG_DYN_RING; i += (uint32_t)G) st[SWG_DYN_MAXES + i] = 0u;
+    }
     __syncthreads();
 
+    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
     CellsDiag<K, WIDE> cells;
     cells.reset();
-    uint32_t tok = 0u, m_out = Z, b_out = Z, c_out = Z;
-    uint2 cur = make_uint2(0u, 0u), nxt = make_uint2(0u, 0u);
+    uint32_t tok = 0u, m_out = Z, b_out = Z;
+    uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
+    uint32_t nlast = 0u;               // last rows this lane has seen = position of its pair in the group's rings
+    uint4 cur = none, nxt = none;
     uint32_t bi = SWG_DYN_NONE;  // leader lane: next token block of the pair it feeds (none: idle)
     // EDGES: block index of cur / nxt (leader), row index travelling with the token, left edges of
     // the current / next block (lanes 0..3 of a group, one row each)
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             drain += 4u;
         }
         cur = nxt;
-        nxt = make_uint2(0u, 0u);
+        nxt = none;
         if (EDGES) {
             bcur = bnxt;
             bnxt = bi;
@@ -905,70 +912,83 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t word = (r & 2) ? cur.y : cur.x;
-            const uint32_t fresh = (r & 1) ? (word >> 16) : (word & 0xFFFFu);
+            const uint32_t fresh = block_row(cur, r);
             uint32_t lm = Z, lb = Z, fresh_ridx = SWG_DYN_NONE;
             if (EDGES) {
                 lm = quad_bcast(ec.x, r);
                 lb = quad_bcast(ec.y, r);
                 fresh_ridx = bcur != SWG_DYN_NONE ? bcur * 4u + (uint32_t)r : SWG_DYN_NONE;
             }
-            uint32_t em, eb, cin;
-            if (G == 16) {
+            uint32_t em, eb;
+            const int Gs = opaque_uniform(G);
+            if (Gs == 16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
                 em = EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, m_out) : dpp_zero<DPP_ROW_SHR1>(m_out);
                 eb = EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, b_out) : dpp_zero<DPP_ROW_SHR1>(b_out);
-                cin = WIDE ? dpp_keep<DPP_ROW_SHR1>(Z, c_out) : dpp_zero<DPP_ROW_SHR1>(c_out);
                 if (EDGES) ridx = dpp_keep<DPP_ROW_SHR1>(fresh_ridx, ridx);
             } else {
                 const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
                 const uint32_t u1 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lm, m_out) : dpp_zero<DPP_WAVE_SHR1>(m_out);
                 const uint32_t u2 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lb, b_out) : dpp_zero<DPP_WAVE_SHR1>(b_out);
-                const uint32_t u3 = WIDE ? dpp_keep<DPP_WAVE_SHR1>(Z, c_out) : dpp_zero<DPP_WAVE_SHR1>(c_out);
                 const uint32_t u4 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(fresh_ridx, ridx) : 0u;
-                if (G == 32) { // lane 32 starts a group too
+                if (Gs == 32) { // lane 32 starts a group too
                     tok = leader ? fresh : u0;
                     em = leader ? lm : u1;
                     eb = leader ? lb : u2;
-                    cin = leader ? Z : u3;
                     if (EDGES) ridx = leader ? fresh_ridx : u4;
                 } else {
                     tok = u0;
                     em = u1;
                     eb = u2;
-                    cin = u3;
                     if (EDGES) ridx = u4;
                 }
             }
-            const uint32_t ox = CH == 4 ? (tok & 0xF8u) : ((tok >> 1) & 0x7Cu);
-            const uint32_t oy = CH == 4 ? ((tok >> 8) & 0xF8u) : ((tok >> 9) & 0x7Cu);
-            const bool special = __builtin_amdgcn_ballot_w64((tok & (SWG_TOK_RESET | SWG_TOK_LAST)) != 0u) != 0ull;
-            uint32_t go_t = p.go, ge_t = p.ge;
+            // Rows with a flag are rare: ONE wave-uniform test (any token above 0xFFFF) keeps their
+            // bookkeeping out of the common step; the recurrence itself is issued once, with per-lane
+            // gap operands that hold the real gap scores except while the lane is on a reset row.
+            const bool special = __builtin_amdgcn_ballot_w64(tok > 0xFFFFu) != 0ull;
             if (special) {
-                const uint32_t fm = 0u - (tok & SWG_TOK_RESET);
+                // reset rows: gap magnitudes of all ones wipe A/G/B, two such rows wipe M
+                uint32_t fm = 0u - ((tok >> 16) & 1u);
+                asm volatile("" : "+v"(fm)); // (keeps this a branch: flattened into selects it costs six instructions on every row)
                 if (WIDE) {
                     cells.wipe(fm);
                 } else {
                     cells.best &= ~fm;
-                    go_t |= fm;
-                    ge_t |= fm;
+                    go_v |= fm;
+                    ge_v |= fm;
                 }
             }
-            const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(smem, base + ox, base + oy, em, eb, go_t, ge_t);
-            c_out = pk_max_i16(cin, cells.best);
-            if (special && tail && (tok & SWG_TOK_LAST)) {
-                uint32_t *st = record();
-                const uint32_t popped = st[3];
-                const uint32_t pr = st[SWG_DYN_RING + (popped & (SWG_DYN_RING - 1u))];
-                st[3] = popped + 1u;
-                if (pr >= p.pair_limit) {
-                    // cannot happen with a well-formed token stream; a stray write must not, either
-                } else if (EDGES) { // one pass of several: the score is the maximum over the passes
-                    atomicMax(p.scores + 2u * pr, (int)((c_out ^ Z) & 0xFFFFu));
-                    atomicMax(p.scores + 2u * pr + 1u, (int)((c_out ^ Z) >> 16));
-                } else {
-                    p.scores[2u * pr] = (int)(c_out & 0xFFFFu);
-                    p.scores[2u * pr + 1u] = (int)(c_out >> 16);
+            const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(smem, base + (tok & 0xFFu), base + ((tok >> 8) & 0xFFu),
+                                                                           em, eb, go_v, ge_v);
+            if (special) {
+                if (!WIDE) {
+                    go_v = p.go;
+                    ge_v = p.ge;
+                }
+                if (tok & SWG_TOK_LAST) {
+                    // the pair's last row on this lane: its maximum joins the pair's slot; the tail lane
+                    // is the last of the group to get here and finishes the pair
+                    uint32_t *st = record();
+                    const uint32_t at = nlast & (SWG_DYN_RING - 1u);
+                    const uint32_t c = cells.best ^ Z;
+                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, c & 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, c >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (tail) {
+                        const uint32_t pr = st[SWG_DYN_RING + at];
+                        const uint32_t sx = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t sy = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at + 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (pr >= p.pair_limit) {
+                            // cannot happen with a well-formed token stream; a stray write must not, either
+                        } else if (EDGES) { // one pass of several: the score is the maximum over the passes
+                            atomicMax(p.scores + 2u * pr, (int)sx);
+                            atomicMax(p.scores + 2u * pr + 1u, (int)sy);
+                        } else {
+                            p.scores[2u * pr] = (int)sx;
+                            p.scores[2u * pr + 1u] = (int)sy;
+                        }
+                    }
+                    ++nlast;
                 }
             }
             m_out = e.x;
@@ -1019,14 +1039,14 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
 // its last dword holding the padding residue 0) and three words per sequence.  The layouts the
 // fill kernels read are made from that here, at HBM speed, instead of on the host.
 //
-// Pair tokens (diagonal engine): thread b writes 4-row block b of the pair-major token array.
-// Block k of a pair holds the rows 4k .. 4k+3 of its token stream = two reset rows, then one row
-// per residue of the longer sequence X (row r: residue r - 2), i.e. residues 4k-2 .. 4k+1: the
-// upper half of residue dword k-1 and the lower half of dword k.  Flag bit 1 (last row) goes on
-// the row of X's last residue -- for an empty pair on the second reset row, so that every pair
-// hands its id to the tail lane exactly once.
+// Pair tokens (diagonal engine): thread b writes 4-row block b of the pair-major token array, one
+// 32-bit token per row (see SWG_TOK_*).  Block k of a pair holds the rows 4k .. 4k+3 of its token
+// stream = two reset rows, then one row per residue of the longer sequence X (row r: residue r - 2),
+// i.e. residues 4k-2 .. 4k+1: the upper half of residue dword k-1 and the lower half of dword k.
+// The last-row flag goes on the row of X's last residue -- for an empty pair on the second reset
+// row, so that every pair is finished by the tail lane exactly once.
 __global__ void swg_build_tokens_kernel(const uint32_t *codes, const uint64_t *code_off, const uint32_t *lens,
-                                        const uint32_t *pair_off, uint32_t n_pairs, uint2 *tok)
+                                        const uint32_t *pair_off, uint32_t n_pairs, uint4 *tok)
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n_pairs == 0u || b >= (uint64_t)pair_off[n_pairs]) return;
@@ -1042,16 +1062,17 @@ __global__ void swg_build_tokens_kernel(const uint32_t *codes, const uint64_t *c
     const uint32_t ndx = (lx + 3u) / 4u, ndy = (ly + 3u) / 4u;
     const uint32_t x1 = k < ndx ? cx[k] : 0u, x0 = (k >= 1u && k - 1u < ndx) ? cx[k - 1u] : 0u;
     const uint32_t y1 = k < ndy ? cy[k] : 0u, y0 = (k >= 1u && k - 1u < ndy) ? cy[k - 1u] : 0u;
-    const uint32_t xw = (x1 << 16) | (x0 >> 16), yw = (y1 << 16) | (y0 >> 16);
-    uint32_t t01 = __builtin_amdgcn_perm(yw, xw, 0x05010400u); // rows 0,1: X byte | Y byte << 8 each
-    uint32_t t23 = __builtin_amdgcn_perm(yw, xw, 0x07030602u); // rows 2,3
-    if (k == 0u) t01 |= SWG_TOK_RESET | (SWG_TOK_RESET << 16);
-    const uint32_t last = lx + 1u; // row of X's last residue
-    if (last / 4u == k) {
-        const uint32_t r = last & 3u;
-        if (r < 2u) t01 |= SWG_TOK_LAST << (16u * r); else t23 |= SWG_TOK_LAST << (16u * (r - 2u));
+    const uint32_t xw = (x1 << 16) | (x0 >> 16), yw = (y1 << 16) | (y0 >> 16); // residues 4k-2 .. 4k+1, one byte each
+    uint32_t t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = ((xw >> (8 * r)) & 0xFFu) | (((yw >> (8 * r)) & 0xFFu) << 8);
+    if (k == 0u) {
+        t[0] |= SWG_TOK_RESET;
+        t[1] |= SWG_TOK_RESET;
     }
-    tok[b] = make_uint2(t01, t23);
+    const uint32_t last = lx + 1u; // row of X's last residue
+    if (last / 4u == k) t[last & 3u] |= SWG_TOK_LAST;
+    tok[b] = make_uint4(t[0], t[1], t[2], t[3]);
 }
 
 // Bin image (systolic engine, bin-based int32 kernel): one workgroup per bin, thread s = slot s of
@@ -1068,7 +1089,7 @@ __global__ void swg_build_bins_kernel(const uint32_t *codes, const uint64_t *cod
 }
 
 hipError_t swg_launch_build_tokens(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
-                                   const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint2 *d_tok,
+                                   const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint4 *d_tok,
                                    hipStream_t stream)
 {
     if (n_pairs == 0 || total_blocks == 0) return hipSuccess;
@@ -1463,7 +1484,7 @@ hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int wo
     return hipGetLastError();
 }
 
-int swg_diag_padded_cols(int K) { return K % 4 == 2 ? K : (K + 3) / 4 * 4; }
+int swg_diag_padded_cols(int K) { return (K + 3) / 4 * 4; }
 
 size_t swg_diag_dyn_lds_bytes(int K, int G, int W)
 {

@@ -689,8 +689,8 @@ def test_device_built_tokens_equal_the_host_builder(swg, ctx, n, n_empty, max_le
     assert dev.size == host.size and dev.size > 0
     assert np.array_equal(dev, host), int(np.nonzero(dev != host)[0][0])
     # every pair carries exactly one last-row flag: the tail lane pops one pair id per flag
-    rows = dev.view(np.uint16)
-    assert int(((rows & 2) != 0).sum()) == (db.count + 1) // 2
+    assert int(((dev & 0x20000) != 0).sum()) == (db.count + 1) // 2
+    assert ((dev & 0xFFFC0707) == 0).all()                 # residue bytes are index << 3, flags are bits 16 and 17
     db.close()
 
 

@@ -52,11 +52,10 @@ def kind(op):
     return "memory / other"
 
 
-# rows are unrolled four times; a row begins where the profile address of its token is formed:
-# the first v_and_b32 with 0xf8 after a backward branch, and ends before the next one
-starts = [i for i, l in enumerate(body) if (parse(l) or ("", ""))[0] == "v_and_b32_e32" and "0xf8" in l
-          and not any("0xf8" in body[j] for j in range(max(0, i - 3), i))]
-a, b = starts[0], starts[1]
+# rows are unrolled four times; a row's profile addresses are formed by two SDWA adds (residue bytes 0
+# and 1 of the token): a row is taken from one BYTE_0 add to the next
+starts = [i for i, l in enumerate(body) if "v_add_u32_sdwa" in l and "BYTE_0" in l]
+a, b = starts[1], starts[2]
 mix = collections.Counter()
 others = []
 for l in body[a:b]:
