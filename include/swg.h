@@ -182,6 +182,21 @@ int swg_search_begin(swg_ctx *ctx, const swg_db *db, int want_scores, size_t k, 
 int swg_search_end(swg_ctx *ctx, int ticket, int32_t *scores_out, swg_hit *topk_out, size_t *n_hits,
                    swg_stats *stats);
 
+/* Many queries against one resident database in ONE pass of the hot path.  The reference takes a
+ * single query per run (src/alignment_cmdline.c:381-396); its report says the design "extends
+ * naturally" to many-to-many (Final Report p.7).  Query i is queries[q_offsets[i] .. q_offsets[i+1])
+ * (table indices, as swg_set_query takes them); the scoring system is the context's, the context's own
+ * query is left as it was.  All queries of a batch share one launch per class: a database too small to
+ * fill the GPU with one query fills it with many.  Batches that cannot take that path (a query of
+ * several passes, scores that may pass 32767, gap scores outside the packed int16 form, engine
+ * options) are searched one query after another: same results.
+ *   scores_out  NULL, or n_queries rows of swg_db_total_count(db) int32 by ORIGINAL database index;
+ *   topk_out/k  NULL/0, or n_queries rows of k hits; n_hits NULL or n_queries counts;
+ *   stats       NULL, or ONE record for the whole batch (times and cells summed). */
+int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *queries, const uint64_t *q_offsets,
+                     size_t n_queries, int32_t *scores_out, swg_hit *topk_out, size_t k, size_t *n_hits,
+                     swg_stats *stats);
+
 /* Reference-shaped replay of the call site itself: n_batches 16-lane batches
  * exactly as `alignment_fill_matrices` receives them -- db_idx_t is
  * aligner_t.seq_b_batch_indexes, [max_len][16] int8 (src/alignment.h:28,

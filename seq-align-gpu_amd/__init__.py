@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "swg_create", "swg_destroy", "swg_last_error", "swg_global_error", "swg_abi_version",
     "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_pack_shard", "swg_db_upload",
     "swg_db_free", "swg_db_save", "swg_db_load", "swg_db_count", "swg_db_total_count", "swg_db_residues",
-    "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_search_begin", "swg_search_end",
+    "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_search_begin", "swg_search_end", "swg_search_multi",
     "swg_fill_batches16", "swg_align_hits", "swg_align_ops_bound", "swg_hit_key",
     "swg_key_hit", "swg_topk_merge_keys",
     "swg_group_create", "swg_group_destroy", "swg_group_size", "swg_group_last_error", "swg_group_set_option",
@@ -129,6 +129,7 @@ _sig("swg_db_order", C.POINTER(C.c_uint32), [_vp])
 _sig("swg_search", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)])
 _sig("swg_search_begin", C.c_int, [_vp, _vp, C.c_int, C.c_size_t, C.POINTER(C.c_int)])
 _sig("swg_search_end", C.c_int, [_vp, C.c_int, _vp, _vp, C.POINTER(C.c_size_t), C.POINTER(Stats)])
+_sig("swg_search_multi", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, C.POINTER(Stats)])
 _sig("swg_fill_batches16", C.c_int, [_vp, C.POINTER(Batch16), C.c_size_t, C.POINTER(C.c_double)])
 _sig("swg_align_hits", C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t])
 _sig("swg_align_ops_bound", C.c_size_t, [_vp, _vp])
@@ -425,6 +426,24 @@ class Context:
                             C.cast(hits, _vp) if k else None, k, C.byref(nh), C.byref(st))
         _check(rc, self.handle)
         return scores, [(int(hits[i].score), int(hits[i].index)) for i in range(nh.value)], st.as_dict()
+
+    def search_multi(self, db, queries, k=0, want_scores=True):
+        """Several queries (list of index arrays) against db in one pass -> (scores int32[nq, total] or None,
+        hits: list of lists, stats dict)."""
+        nq = len(queries)
+        qoff = np.zeros(nq + 1, dtype=np.uint64)
+        qoff[1:] = np.cumsum([len(q) for q in queries])
+        qflat = np.ascontiguousarray(np.concatenate(queries) if nq else np.zeros(0), dtype=np.int8)
+        scores = np.zeros((nq, db.total_count), dtype=np.int32) if want_scores else None
+        hits = (Hit * max(k * nq, 1))()
+        nh = (C.c_size_t * max(nq, 1))()
+        st = Stats()
+        rc = lib.swg_search_multi(self.handle, db.handle, qflat.ctypes.data_as(_vp), qoff.ctypes.data_as(_vp), nq,
+                                  scores.ctypes.data_as(_vp) if want_scores else None, C.cast(hits, _vp) if k else None, k,
+                                  C.cast(nh, _vp), C.byref(st))
+        _check(rc, self.handle)
+        out = [[(int(hits[i * k + j].score), int(hits[i * k + j].index)) for j in range(nh[i])] for i in range(nq)]
+        return scores, out, st.as_dict()
 
     def search_begin(self, db, k=0, want_scores=False):
         """Queue a search; returns a ticket for search_end / search_end_keys."""

@@ -1413,6 +1413,287 @@ extern "C" int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out, s
 }
 
 // ---------------------------------------------------------------------------
+// many queries against one resident database in one pass
+// ---------------------------------------------------------------------------
+// The reference runs one query per process (src/alignment_cmdline.c:381-396 reads a single query
+// record); its report says the design "extends naturally" to many-to-many (Final Report p.7).  Here
+// that is one launch per class for a whole batch of queries: row y of the grid works for query y (its
+// own profile, its own pair queue, its own score array), so a database too small to fill the chip
+// with one query -- where a search lasts as long as its longest pair's chain of rows -- fills it with
+// many.  Queries that cannot take this path (several passes, scores that may saturate int16, gap
+// scores outside the packed form, options that ask for another engine) are searched one after
+// another with swg_search: same results, no batching.
+namespace {
+struct MultiBufs {
+    int8_t *d_q = nullptr;
+    uint32_t *d_qoff = nullptr;
+    uint8_t *d_prof[2] = {nullptr, nullptr};
+    int32_t *d_scores = nullptr;
+    uint32_t *d_cnt = nullptr;
+    ~MultiBufs()
+    {
+        (void)hipFree(d_q);
+        (void)hipFree(d_qoff);
+        (void)hipFree(d_prof[0]);
+        (void)hipFree(d_prof[1]);
+        (void)hipFree(d_scores);
+        (void)hipFree(d_cnt);
+    }
+};
+} // namespace
+
+static void multi_deliver(const swg_db *db, const int32_t *h_scores, size_t n_slots, int32_t *scores_out, swg_hit *topk_out,
+                          size_t k, size_t *n_hits)
+{
+    if (scores_out)
+        for (size_t i = 0; i < n_slots; ++i) {
+            const uint32_t oi = db->order[i];
+            if (oi != 0xFFFFFFFFu) scores_out[oi] = h_scores[i];
+        }
+    if (k > 0 && topk_out) {
+        std::vector<uint64_t> keys;
+        keys.reserve(db->n_local);
+        for (size_t i = 0; i < n_slots; ++i) {
+            const uint32_t oi = db->order[i];
+            if (oi != 0xFFFFFFFFu) keys.push_back(swg_hit_key(h_scores[i], oi));
+        }
+        const size_t m = std::min(k, keys.size());
+        std::partial_sort(keys.begin(), keys.begin() + m, keys.end(), std::greater<uint64_t>());
+        for (size_t i = 0; i < m; ++i) swg_key_hit(keys[i], &topk_out[i]);
+        if (n_hits) *n_hits = m;
+    } else if (n_hits) {
+        *n_hits = 0;
+    }
+}
+
+extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *queries, const uint64_t *q_offsets,
+                                size_t n_queries, int32_t *scores_out, swg_hit *topk_out, size_t k, size_t *n_hits,
+                                swg_stats *stats)
+{
+    if (!ctx || !db || (n_queries && (!queries || !q_offsets)))
+        return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_multi: NULL argument");
+    if (k > 0 && !topk_out) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_multi: k > 0 but topk_out NULL");
+    if (!ctx->have_scoring) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_multi: no scoring set");
+    if (db->device != ctx->device || !db->d_codes)
+        return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_multi: database is not resident on device %d", ctx->device);
+    for (const SwgSlot &sl : ctx->slots)
+        if (sl.busy) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_multi: searches are in flight on this context");
+    swg_stats st;
+    memset(&st, 0, sizeof st);
+    size_t lq_max = 0;
+    for (size_t i = 0; i < n_queries; ++i) {
+        if (q_offsets[i + 1] <= q_offsets[i])
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_multi: query %zu is empty or the offsets are not increasing", i);
+        const size_t lq = (size_t)(q_offsets[i + 1] - q_offsets[i]);
+        if (lq > (1u << 24)) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_multi: query %zu too long", i);
+        lq_max = std::max(lq_max, lq);
+        for (uint64_t j = q_offsets[i]; j < q_offsets[i + 1]; ++j)
+            if (queries[j] < 1 || queries[j] > 31)
+                return swg_set_ctx_error(ctx, SWG_ERR_RESIDUE, "swg_search_multi: residue index %d in query %zu outside 1..31",
+                                         queries[j], i);
+        st.cells += (uint64_t)lq * db->residues;
+        st.bytes_alg += db->residues + 8ull * db->n_local + 32ull * lq + 1024ull;
+    }
+    if (stats) *stats = st;
+    if (n_queries == 0) return SWG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
+    const size_t n_total = db->n_total;
+
+    // ---- can the batch go through one launch? ------------------------------------------------
+    const int go = ctx->gap_open + ctx->gap_extend, ge = ctx->gap_extend;
+    bool fast = ctx->gap_open <= 0 && ctx->gap_extend <= 0 && -go <= 32767 && ctx->opt_force_bits != 32 &&
+                ctx->opt_engine != 1 && ctx->opt_dynamic != 0 && db->n_bins > 0 && n_queries > 1 && ctx->opt_cols == 0 &&
+                ctx->opt_group == 0 && ctx->opt_max_waves == 0 && ctx->opt_workgroups == 0;
+    SwgDiagWork wk;
+    const size_t Qb_max = 256; // queries per launch
+    if (fast) {
+        // no score of any query may reach the int16 ceiling (the batch path has no re-score)
+        int smax = 0;
+        for (int a = 0; a < 32; ++a)
+            for (int b = 0; b < 32; ++b) smax = std::max<int>(smax, ctx->sub[a][b]);
+        const uint64_t longest = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK;
+        for (size_t i = 0; i < n_queries && fast; ++i) {
+            uint64_t qbound = 0;
+            const uint64_t lq = q_offsets[i + 1] - q_offsets[i];
+            for (uint64_t j = q_offsets[i]; j < q_offsets[i + 1]; ++j) {
+                int best = 0;
+                for (int b = 1; b < 32; ++b) best = std::max<int>(best, ctx->sub[(uint8_t)queries[j] & 31][b]);
+                qbound += (uint64_t)best;
+            }
+            if (std::min<uint64_t>(qbound, std::min<uint64_t>(lq, longest) * (uint64_t)smax) >= 32767ull) fast = false;
+        }
+    }
+    if (fast) {
+        int rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db));
+        if (rc != SWG_OK) return rc;
+        fast = db->ptok.ok &&
+               swg_plan_diag_work(db, lq_max, ctx->n_cu, 0, 0, 0, ctx->opt_long_split, true, true, &wk,
+                                  (double)std::min(n_queries, Qb_max)) > 0;
+        for (int c = 0; fast && c < wk.n_classes; ++c)
+            fast = wk.plan[c].npass == 1 && diag_class_is_dynamic(ctx, db, wk.plan[c]) && (size_t)wk.plan[c].G * wk.plan[c].K >= lq_max;
+    }
+    if (!fast) {
+        // one after another; the context's own query is put back afterwards
+        const std::vector<int8_t> keep = ctx->query;
+        int rc = SWG_OK;
+        swg_stats one;
+        for (size_t i = 0; i < n_queries && rc == SWG_OK; ++i) {
+            rc = swg_set_query(ctx, queries + q_offsets[i], (size_t)(q_offsets[i + 1] - q_offsets[i]));
+            if (rc == SWG_OK)
+                rc = swg_search(ctx, db, scores_out ? scores_out + i * n_total : nullptr, topk_out ? topk_out + i * k : nullptr, k,
+                                n_hits ? n_hits + i : nullptr, &one);
+            if (rc == SWG_OK) {
+                st.fill_ms += one.fill_ms;
+                st.rescore_ms += one.rescore_ms;
+                st.topk_ms += one.topk_ms;
+                st.total_ms += one.total_ms;
+                st.n_rescored += one.n_rescored;
+                st.cells_padded += one.cells_padded;
+                st.path_bits = one.path_bits;
+                st.engine = one.engine;
+                st.cols_per_wave = one.cols_per_wave;
+                st.group_lanes = one.group_lanes;
+                st.waves = one.waves;
+                st.passes = one.passes;
+                st.workgroups = one.workgroups;
+                st.work_queue = one.work_queue;
+            }
+        }
+        if (!keep.empty()) {
+            const int rq = swg_set_query(ctx, keep.data(), keep.size());
+            if (rc == SWG_OK) rc = rq;
+        } else {
+            ctx->query.clear();
+        }
+        if (stats) *stats = st;
+        return rc;
+    }
+
+    // ---- one launch per class for up to Qb_max queries ----------------------------------------
+    const SwgPairTokens &T = db->ptok;
+    const uint32_t gm = (uint32_t)(-go) & 0xFFFFu, em = (uint32_t)(-ge) & 0xFFFFu;
+    const uint32_t cnt_class = SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE; // queue dwords of one class of one query
+    MultiBufs B;
+    std::vector<int32_t> h_scores;
+    std::vector<uint32_t> qoff32;
+    hipStream_t s = ctx->stream;
+    ctx->cur = &ctx->slots[0];
+    for (size_t q0 = 0; q0 < n_queries; q0 += Qb_max) {
+        const size_t Qb = std::min(Qb_max, n_queries - q0);
+        const uint64_t qbytes = q_offsets[q0 + Qb] - q_offsets[q0];
+        try {
+            qoff32.resize(Qb + 1);
+            h_scores.resize(Qb * n_slots);
+        } catch (const std::exception &) {
+            return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_search_multi: out of host memory");
+        }
+        for (size_t i = 0; i <= Qb; ++i) qoff32[i] = (uint32_t)(q_offsets[q0 + i] - q_offsets[q0]);
+        if (q0 == 0) {
+            const size_t cnt_dwords = Qb_max * 2 * cnt_class + 2 * SWG_DYN_SIMD_SLOTS;
+            HIP_TRY(ctx, hipMalloc(&B.d_cnt, cnt_dwords * 4));
+            HIP_TRY(ctx, hipMalloc(&B.d_scores, std::min(Qb_max, n_queries) * n_slots * 4));
+            HIP_TRY(ctx, hipMalloc(&B.d_qoff, (Qb_max + 1) * 4));
+            for (int c = 0; c < wk.n_classes; ++c)
+                HIP_TRY(ctx, hipMalloc(&B.d_prof[c], std::min(Qb_max, n_queries) * (size_t)wk.plan[c].G *
+                                                         swg_diag_padded_cols(wk.plan[c].K) * 64));
+        }
+        (void)hipFree(B.d_q);
+        B.d_q = nullptr;
+        HIP_TRY(ctx, hipMalloc(&B.d_q, std::max<uint64_t>(4, qbytes)));
+        HIP_TRY(ctx, hipMemcpyAsync(B.d_q, queries + q_offsets[q0], qbytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(B.d_qoff, qoff32.data(), (Qb + 1) * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemsetAsync(B.d_scores, 0, Qb * n_slots * 4, s));
+        HIP_TRY(ctx, hipMemsetAsync(B.d_cnt, 0, (Qb_max * 2 * cnt_class + 2 * SWG_DYN_SIMD_SLOTS) * 4, s));
+        for (int c = 0; c < wk.n_classes; ++c) {
+            const SwgDiagPlan &pl = wk.plan[c];
+            HIP_TRY(ctx, swg_launch_build_profiles_multi(ctx->d_sub, B.d_q, B.d_qoff, (uint32_t)Qb,
+                                                         (uint32_t)(pl.G * swg_diag_padded_cols(pl.K)), pl.K,
+                                                         swg_diag_padded_cols(pl.K), B.d_prof[c], s));
+        }
+        // workgroups per query: the chip's resident workgroups shared out over the batch
+        int wgs[2] = {1, 1};
+        uint64_t groups0 = 1;
+        for (int c = 0; c < wk.n_classes; ++c) {
+            const SwgDiagPlan &pl = wk.plan[c];
+            const SwgKernelInfo info = swg_diag_variant_info(pl.variant);
+            const size_t lds = swg_diag_dyn_lds_bytes(pl.K, pl.G, pl.W);
+            const int per_cu = std::max(1, std::min<int>(info.max_waves / pl.W, (int)((160 * 1024) / lds)));
+            int total = ctx->n_cu * per_cu;
+            if (wk.n_classes == 2) total = c == 1 ? ctx->n_cu : std::max(ctx->n_cu, total - ctx->n_cu); // one wavefront per SIMD for the long class
+            const uint64_t pairs = wk.pair_end[c] - wk.pair_begin[c];
+            const uint64_t per_wg = (uint64_t)pl.W * (64 / pl.G);
+            wgs[c] = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)total / Qb, (pairs + per_wg - 1) / per_wg));
+            if (c == 0) groups0 = (uint64_t)wgs[0] * Qb * per_wg;
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
+        if (wk.n_classes == 2) {
+            HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[6], s));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->cur->ev[6], 0));
+        }
+        for (int c = wk.n_classes - 1; c >= 0; --c) {
+            const SwgDiagPlan &pl = wk.plan[c];
+            SwgDiagDynParams q;
+            memset(&q, 0, sizeof q);
+            q.tok = T.d_tok;
+            q.pair_off = T.d_pair_off;
+            q.q_begin = (uint32_t)wk.pair_begin[c];
+            q.q_end = (uint32_t)wk.pair_end[c];
+            q.queue = B.d_cnt + (size_t)c * cnt_class;
+            q.queue_stride = 2 * cnt_class;
+            q.profile = B.d_prof[c];
+            q.profile_stride = (uint64_t)pl.G * swg_diag_padded_cols(pl.K) * 64;
+            q.scores = B.d_scores;
+            q.score_stride = n_slots;
+            q.pair_limit = (uint32_t)(n_slots / 2);
+            q.G = (uint32_t)pl.G;
+            q.go = gm | (gm << 16);
+            q.ge = em | (em << 16);
+            if (c == 0) {
+                const uint64_t blocks = (uint64_t)(T.pair_blocks_prefix[wk.pair_end[0]] - T.pair_blocks_prefix[wk.pair_begin[0]]) * Qb;
+                q.prio_blocks = (uint32_t)std::max<uint64_t>(8, (uint64_t)(ctx->opt_prio_share * 0.01 * (double)blocks / (double)groups0));
+            }
+            q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
+            q.simd_ranks = B.d_cnt + Qb_max * 2 * cnt_class + (size_t)c * SWG_DYN_SIMD_SLOTS;
+            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, false, false, pl.W, wgs[c], q, c == 1 ? ctx->stream2 : s, (int)Qb));
+        }
+        if (wk.n_classes == 2) {
+            HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[7], ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->cur->ev[7], 0));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
+        HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), B.d_scores, Qb * n_slots * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, spin_sync(ctx, s));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[1], ctx->cur->ev[2]));
+        st.fill_ms += ms;
+        st.total_ms += ms;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < Qb; ++i)
+            multi_deliver(db, h_scores.data() + i * n_slots, n_slots, scores_out ? scores_out + (q0 + i) * n_total : nullptr,
+                          topk_out ? topk_out + (q0 + i) * k : nullptr, k, n_hits ? n_hits + q0 + i : nullptr);
+        st.topk_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        st.workgroups = wgs[0] * (int)Qb;
+        st.streams = (int32_t)groups0;
+    }
+    st.path_bits = 16;
+    st.engine = 2;
+    st.work_queue = 1;
+    st.cols_per_wave = wk.plan[0].K;
+    st.group_lanes = wk.plan[0].G;
+    st.waves = wk.plan[0].W;
+    st.passes = 1;
+    if (wk.n_classes == 2) {
+        st.long_pairs = (int32_t)(wk.pair_end[1] - wk.pair_begin[1]);
+        st.long_cols_per_lane = wk.plan[1].K;
+    }
+    for (int c = 0; c < wk.n_classes; ++c)
+        st.cells_padded += 2ull * wk.plan[c].G * wk.plan[c].K * diag_class_blocks(ctx, db, wk, c) * 4ull * n_queries;
+    if (stats) *stats = st;
+    return SWG_OK;
+}
+
+// ---------------------------------------------------------------------------
 // reference-shaped replay (16-lane batches as alignment_fill_matrices gets them)
 // ---------------------------------------------------------------------------
 extern "C" int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches,

@@ -111,13 +111,18 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
 }
 
 int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                             long opt_long_split, bool allow_split, bool work_queue, std::vector<SwgDiagWork> *cands)
+                             long opt_long_split, bool allow_split, bool work_queue, std::vector<SwgDiagWork> *cands,
+                             double copies)
 {
+    // copies > 1: the same database is searched by that many queries in ONE launch (swg_search_multi):
+    // all throughput terms grow with it, the longest chain of rows does not
     cands->clear();
     const uint64_t n_pairs = swg_db_pair_count(db);
     if (n_pairs == 0) return 0;
+    if (copies < 1.0) copies = 1.0;
     uint64_t longest = 0;
-    const uint64_t rows_all = swg_db_pair_rows(db, 0, n_pairs, &longest);
+    const uint64_t rows_once = swg_db_pair_rows(db, 0, n_pairs, &longest);
+    const double rows_all = (double)rows_once * copies;
     const bool have_long = allow_split && opt_long_split >= 0;
     const double simds = 4.0 * n_cu;
     const int groups[3] = {16, 32, 64};
@@ -163,33 +168,34 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                 const uint64_t hw_streams = (uint64_t)n_cu * per_cu * spw;
                 // (a long class beside a multi-pass queue launch would need its own edge buffers: not built)
                 for (int split = 0; split <= (have_long && !(dynamic && npass > 1) ? 3 : 0); ++split) {
-                    uint64_t n_long = 0, rows_long = 0, longest_bulk = longest, longest_long = 0;
-                    uint64_t streams0 = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, n_pairs));
+                    uint64_t n_long = 0, longest_bulk = longest, longest_long = 0;
+                    double rows_long = 0;
+                    uint64_t streams0 = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, (uint64_t)((double)n_pairs * copies)));
                     streams0 = (streams0 + spw - 1) / spw * spw;
                     if (split) {
                         if (split == 3 && opt_long_split > 0) continue;
                         const double frac = split == 3 ? 0.6 : 0.33;
                         uint64_t thr = opt_long_split > 0 ? (uint64_t)opt_long_split
-                                                          : (uint64_t)(frac * (double)rows_all / (double)streams0);
+                                                          : (uint64_t)(frac * rows_all / (double)streams0);
                         if (dynamic && opt_long_split <= 0) {
                             // longest pair a fair-share wavefront finishes within the whole search
-                            const double all_cycles = (double)rows_all / NG * instr * cps / simds;
+                            const double all_cycles = rows_all / NG * instr * cps / simds;
                             thr = (uint64_t)((split == 3 ? 0.65 : 0.9) * all_cycles / (instr * cps * eff_wps));
                         }
                         thr = std::max<uint64_t>(thr, 64);
                         if (longest <= thr) continue;
                         n_long = swg_db_pairs_longer_than(db, thr);
                         if (n_long == 0 || n_long * 4 > n_pairs) continue;
-                        rows_long = swg_db_pair_rows(db, 0, n_long, &longest_long);
+                        rows_long = (double)swg_db_pair_rows(db, 0, n_long, &longest_long) * copies;
                         longest_bulk = 2ull + db->lens[2 * n_long];
                     }
                     const uint64_t n_bulk = n_pairs - n_long;
-                    const uint64_t rows_bulk = rows_all - rows_long;
-                    uint64_t streams = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, n_bulk));
+                    const double rows_bulk = rows_all - rows_long;
+                    uint64_t streams = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, (uint64_t)((double)n_bulk * copies)));
                     streams = (streams + spw - 1) / spw * spw;
                     // (a) throughput: SIMD-cycles of both classes over all SIMDs
-                    double work = (double)rows_bulk / NG * npass * instr * cps;
-                    double crit = (std::max<double>((double)rows_bulk / streams, (double)longest_bulk) + G) * npass *
+                    double work = rows_bulk / NG * npass * instr * cps;
+                    double crit = (std::max<double>(rows_bulk / streams, (double)longest_bulk) + G) * npass *
                                   instr * cps * eff_wps;
                     uint64_t lstreams = 0;
                     SwgDiagPlan lp;
@@ -209,12 +215,12 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                         }
                         const uint64_t lspw = 4ull * (64 / lp.G);
                         // static: two pairs per stream to balance; queue: a wavefront on every SIMD
-                        lstreams = std::max<uint64_t>(1, std::min<uint64_t>(dynamic ? n_long : (n_long + 1) / 2,
+                        lstreams = std::max<uint64_t>(1, std::min<uint64_t>(dynamic ? (uint64_t)((double)n_long * copies) : (n_long + 1) / 2,
                                                                             (uint64_t)n_cu * lspw));
                         lstreams = (lstreams + lspw - 1) / lspw * lspw;
                         const double linstr = instr_per_row(lp.K, lp.G);
-                        work += (double)rows_long / (64 / lp.G) * lp.npass * linstr * cps;
-                        const double lcrit = (std::max<double>((double)rows_long / lstreams, (double)longest_long) + lp.G) *
+                        work += rows_long / (64 / lp.G) * lp.npass * linstr * cps;
+                        const double lcrit = (std::max<double>(rows_long / lstreams, (double)longest_long) + lp.G) *
                                              lp.npass * linstr * kHotCycles;
                         crit = std::max(crit, lcrit);
                     }
@@ -268,12 +274,12 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
 }
 
 int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk)
+                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk, double copies)
 {
     std::vector<SwgDiagWork> c;
     wk->n_classes = 0;
     if (swg_plan_diag_candidates(db, lq, n_cu, opt_cols, opt_group, opt_waves, opt_long_split, allow_split, work_queue,
-                                 &c) > 0)
+                                 &c, copies) > 0)
         *wk = c[0];
     return wk->n_classes;
 }

@@ -208,11 +208,11 @@ extern "C" int swg_debug_pair_tokens(swg_ctx *ctx, swg_db *db, int from_host, ui
 // geometry of both classes for one query length on one device; returns the number of
 // classes (0: the diagonal engine cannot run this with the given options)
 int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk);
+                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk, double copies = 1.0);
 // every geometry the model considered, best estimate first (the autotuner times the first few)
 int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
                              long opt_long_split, bool allow_split, bool work_queue,
-                             std::vector<SwgDiagWork> *cands);
+                             std::vector<SwgDiagWork> *cands, double copies = 1.0);
 // 0 on success; -1 when the database is too large for 32-bit block offsets.  tok == NULL: only
 // pair_off (the tokens themselves are built on the device, swg_launch_build_tokens); otherwise also
 // the host builder's token image, which the tests compare the device's with.

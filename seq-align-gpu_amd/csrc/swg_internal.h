@@ -74,6 +74,11 @@ struct SwgDiagDynParams {
     uint2 *edge_out;          // ... right edge per row for the next pass (null: last)
     uint32_t turn_levels;     // priorities the other wavefronts rotate through: 3 beside a long class, else 4
     uint64_t *trace;          // diagnostics (SWG_TRACE) or null
+    // several queries in one launch (swg_search_multi): grid.y = query; workgroup row y reads profile +
+    // y * profile_stride (bytes), takes pairs off queue + y * queue_stride (dwords) and writes scores +
+    // y * score_stride (entries).  All zero for a single query.
+    uint64_t profile_stride, score_stride;
+    uint32_t queue_stride;
 };
 
 struct SwgKernelInfo {
@@ -104,7 +109,12 @@ hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int wo
                            const SwgDiagParams &p, hipStream_t stream);
 size_t swg_diag_dyn_lds_bytes(int K, int G, int W);
 hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int workgroups, const SwgDiagDynParams &p,
-                               hipStream_t stream);
+                               hipStream_t stream, int n_queries = 1);
+// profiles of n_queries queries (query i = queries[q_off[i] .. q_off[i+1])) in one launch: query i's
+// profile of ncols layout columns goes to d_profiles + i * ncols * 32 * 2 (int16)
+hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off,
+                                           uint32_t n_queries, uint32_t ncols, int k_real, int k_padded,
+                                           uint8_t *d_profiles, hipStream_t stream);
 
 // profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
 // col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.

@@ -777,8 +777,12 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         return reinterpret_cast<uint32_t *>(smem + slice) + (((uint32_t)w << (6 - gshift)) + (l >> gshift)) * SWG_DYN_STATE;
     };
     const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
+    // several queries in one launch: row y of the grid works for query y (its profile, its queue, its scores)
+    const uint8_t *profile = p.profile + (size_t)blockIdx.y * p.profile_stride;
+    uint32_t *const queue = p.queue + (size_t)blockIdx.y * p.queue_stride;
+    int32_t *const scores = p.scores + (size_t)blockIdx.y * p.score_stride;
     for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
-        *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(p.profile + o);
+        *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(profile + o);
     {
         uint32_t *st = record();
         if (g < 4) st[g] = 0u; // every group is due at block 0
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                         tried = 0u;
                     }
                     const uint32_t shard = (blockIdx.x + tried) & (SWG_DYN_SHARDS - 1u);
-                    uint32_t *ctr = (second ? p.queue2 : p.queue) + shard * SWG_DYN_SHARD_STRIDE;
+                    uint32_t *ctr = (second ? p.queue2 : queue) + shard * SWG_DYN_SHARD_STRIDE;
                     const uint32_t cand = (second ? p.q2_begin : p.q_begin) + shard + SWG_DYN_SHARDS * atomicAdd(ctr, 1u);
                     if (cand < (second ? p.q2_end : p.q_end)) {
                         nq = cand;
@@ -981,11 +985,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                         if (pr >= p.pair_limit) {
                             // cannot happen with a well-formed token stream; a stray write must not, either
                         } else if (EDGES) { // one pass of several: the score is the maximum over the passes
-                            atomicMax(p.scores + 2u * pr, (int)sx);
-                            atomicMax(p.scores + 2u * pr + 1u, (int)sy);
+                            atomicMax(scores + 2u * pr, (int)sx);
+                            atomicMax(scores + 2u * pr + 1u, (int)sy);
                         } else {
-                            p.scores[2u * pr] = (int)sx;
-                            p.scores[2u * pr + 1u] = (int)sy;
+                            scores[2u * pr] = (int)sx;
+                            scores[2u * pr + 1u] = (int)sy;
                         }
                     }
                     ++nlast;
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         if (!hot && (blocks & (SWG_DYN_TURN_EVERY - 1u)) == 0u) take_turn();
     }
     if (p.trace && lane == 0) {
-        uint64_t *t = p.trace + (size_t)(blockIdx.x * W + w) * 4u;
+        uint64_t *t = p.trace + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * W + w) * 4u;
         t[0] = t_start;
         t[1] = wall_clock64();
         t[2] = (uint64_t)blocks | ((uint64_t)events << 32) | (event_ticks << 44);
@@ -1030,6 +1034,33 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
         reinterpret_cast<int16_t *>(out)[e] = pad ? (int16_t)-32768 : (int16_t)v;
     else
         reinterpret_cast<int32_t *>(out)[e] = pad ? -(1 << 29) : v;
+}
+
+// The same for several queries at once (swg_search_multi): grid.y = query; int16, 4-column chunks.
+__global__ void swg_build_profiles_multi_kernel(const int8_t *sub, const int8_t *queries, const uint32_t *q_off,
+                                                uint32_t ncols, uint32_t k_real, uint32_t k_padded, uint8_t *out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
+    if (t >= ncols * 32u) return;
+    const uint32_t qi = blockIdx.y;
+    const int8_t *query = queries + q_off[qi];
+    const uint32_t lq = q_off[qi + 1u] - q_off[qi];
+    const uint32_t col = t >> 5, code = t & 31u;
+    const uint32_t j = col % k_padded, qcol = (col / k_padded) * k_real + j;
+    const bool pad = (j >= k_real) || (qcol >= lq) || (code == 0u);
+    const int v = pad ? 0 : (int)sub[(int)query[qcol] * 32 + (int)code];
+    const size_t e = (size_t)(col / 4u) * 128u + code * 4u + (col % 4u); // [col/4][32][4]
+    reinterpret_cast<int16_t *>(out + (size_t)qi * ncols * 64u)[e] = pad ? (int16_t)-32768 : (int16_t)v;
+}
+
+hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off,
+                                           uint32_t n_queries, uint32_t ncols, int k_real, int k_padded,
+                                           uint8_t *d_profiles, hipStream_t stream)
+{
+    if (n_queries == 0 || ncols == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_build_profiles_multi_kernel, dim3((ncols * 32u + 255u) / 256u, n_queries), dim3(256), 0, stream,
+                       d_sub, d_queries, d_q_off, ncols, (uint32_t)k_real, (uint32_t)k_padded, d_profiles);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -1492,8 +1523,9 @@ size_t swg_diag_dyn_lds_bytes(int K, int G, int W)
 }
 
 hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int workgroups, const SwgDiagDynParams &p,
-                               hipStream_t stream)
+                               hipStream_t stream, int n_queries)
 {
+    if (n_queries < 1 || n_queries > 65535) return hipErrorInvalidValue;
     int n;
     const DiagVariant *v = diag_variants(&n);
     if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
@@ -1504,7 +1536,7 @@ hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int wo
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(workgroups, n_queries), dim3(W * 64), lds, stream, p);
     return hipGetLastError();
 }
 

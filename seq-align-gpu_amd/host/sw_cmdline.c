@@ -353,30 +353,71 @@ next_query:
         free(line);
     }
     if (allq && ++qi < q.n) {
-        /* the database stays resident: only the query (and its profile) changes */
-        const size_t lqi = (size_t)(q.seq_off[qi + 1] - q.seq_off[qi]);
-        if (lqi == 0) {
-            fprintf(stderr, "Error: query #%lu is empty\n", (unsigned long)qi);
-            return EXIT_FAILURE;
+        /* The database stays resident; the remaining queries go through swg_search_multi in chunks (one
+         * launch per class for a whole chunk: a small database is filled with many queries at once),
+         * results are kept per query and printed in order. */
+        static int32_t *mq_scores = NULL;
+        static swg_hit *mq_hits = NULL;
+        static size_t *mq_nhits = NULL;
+        static size_t chunk_first = 0, chunk_n = 0;
+        static double chunk_ms = 0.0;
+        static int8_t *qx = NULL;     /* the chunk's queries as table indices */
+        static uint64_t *qoff = NULL;
+        if (qi >= chunk_first + chunk_n) {
+            size_t budget = ((size_t)256 << 20) / (sizeof(int32_t) * (db.n ? db.n : 1));
+            if (budget < 1) budget = 1;
+            if (budget > 1024) budget = 1024;
+            chunk_first = qi;
+            chunk_n = q.n - qi < budget ? q.n - qi : budget;
+            const size_t nres = (size_t)(q.seq_off[chunk_first + chunk_n] - q.seq_off[chunk_first]);
+            free(qx);
+            free(qoff);
+            qx = (int8_t *)malloc(nres ? nres : 1);
+            qoff = (uint64_t *)malloc((chunk_n + 1) * sizeof(uint64_t));
+            free(mq_scores);
+            free(mq_hits);
+            free(mq_nhits);
+            mq_scores = (int32_t *)calloc(chunk_n * (db.n ? db.n : 1), sizeof(int32_t));
+            mq_hits = (swg_hit *)calloc(chunk_n * (topk ? (size_t)topk : 1), sizeof(swg_hit));
+            mq_nhits = (size_t *)calloc(chunk_n, sizeof(size_t));
+            if (!qx || !qoff || !mq_scores || !mq_hits || !mq_nhits) return EXIT_FAILURE;
+            for (size_t i = 0; i <= chunk_n; i++) qoff[i] = q.seq_off[chunk_first + i] - q.seq_off[chunk_first];
+            for (size_t i = 0; i < chunk_n; i++) {
+                const size_t lqi = (size_t)(qoff[i + 1] - qoff[i]);
+                if (lqi == 0) {
+                    fprintf(stderr, "Error: query #%lu is empty\n", (unsigned long)(chunk_first + i));
+                    return EXIT_FAILURE;
+                }
+                for (size_t c = 0; c < lqi; c++) {
+                    const char ch = q.seq[q.seq_off[chunk_first + i] + c];
+                    const int v = swg_letter_index((unsigned char)ch);
+                    if (v < 0) die_illegal(ch);
+                    qx[qoff[i] + c] = (int8_t)v;
+                }
+                swg_query_sanitize(&sc, qx + qoff[i], lqi);
+            }
+            swg_stats st;
+            memset(&st, 0, sizeof st);
+            const int rc = swg_search_multi(ctx, pdb, qx, qoff, chunk_n, mq_scores, mq_hits, (size_t)topk, mq_nhits, &st);
+            if (rc != SWG_OK) {
+                fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
+                return EXIT_FAILURE;
+            }
+            chunk_ms = st.total_ms / (double)chunk_n; /* the chunk's device time, shared out over its queries */
+            if (timing)
+                fprintf(stderr, "[timing] %lu queries in one pass: %.3f ms of fill, %.1f GCUPS\n", (unsigned long)chunk_n,
+                        st.fill_ms, st.fill_ms > 0 ? (double)st.cells / (st.fill_ms * 1e-3) / 1e9 : 0.0);
         }
-        int8_t *qx = (int8_t *)malloc(lqi);
-        if (!qx) return EXIT_FAILURE;
-        for (size_t c = 0; c < lqi; c++) {
-            const int v = swg_letter_index((unsigned char)q.seq[q.seq_off[qi] + c]);
-            if (v < 0) die_illegal(q.seq[q.seq_off[qi] + c]);
-            qx[c] = (int8_t)v;
-        }
-        swg_query_sanitize(&sc, qx, lqi);
-        swg_stats st;
-        memset(&st, 0, sizeof st);
-        int rc = swg_set_query(ctx, qx, lqi);
-        if (rc == SWG_OK) rc = swg_search(ctx, pdb, scores, hits, (size_t)topk, &n_hits, &st);
-        free(qx);
-        if (rc != SWG_OK) {
+        const size_t at = qi - chunk_first;
+        memcpy(scores, mq_scores + at * (db.n ? db.n : 1), db.n * sizeof(int32_t));
+        n_hits = mq_nhits[at];
+        memcpy(hits, mq_hits + at * (topk ? (size_t)topk : 1), n_hits * sizeof(swg_hit));
+        if (align && swg_set_query(ctx, qx + qoff[at], (size_t)(qoff[at + 1] - qoff[at])) != SWG_OK) {
+            /* (the alignments of the hits are made against the context's query) */
             fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
             return EXIT_FAILURE;
         }
-        total_ms = st.total_ms;
+        total_ms = chunk_ms;
         qname = q.names + q.name_off[qi];
         goto next_query;
     }

@@ -453,8 +453,17 @@ def test_full_size_databases_equal_the_reference_itself(swg, ctx, orc, cfg):
     _reset_options(ctx)
     db = swg.Database(flat, off).upload(ctx)
     scores, _, st = ctx.search(db)
-    db.close()
     assert st["engine"] == 2 and st["path_bits"] == 16 and (st["n_rescored"] == 0 or cfg == "config5")
+    if cfg == "config5":
+        # the same search on the path the configuration is named after: plain int16 (sticks at 32767), every
+        # flagged sequence re-scored in int32 -- at full size, all 100 000 scores against the wide form's
+        ctx.set_option("wide16", 0)
+        scores16, _, st16 = ctx.search(db)
+        ctx.set_option("wide16", 1)
+        assert st["n_rescored"] == 0                        # 8192 columns cannot pass 65535: the wide form is exact
+        assert st16["n_rescored"] == planted == int((scores > 32767).sum())
+        assert np.array_equal(scores16, scores)
+    db.close()
     groups = np.arange(0, n // 16, every)
     lens = np.diff(off.astype(np.int64))
     assert all(lens[g * 16] == lens[g * 16:g * 16 + 16].max() for g in groups[:: max(1, len(groups) // 2000)])
@@ -717,3 +726,163 @@ def test_empty_records_mixed_in(swg, ctx, orc):
             assert hits == orc.topk(want, 20)
         db.close()
     _reset_options(ctx)
+
+
+def test_config5_every_sequence_similar(swg, ctx, orc):
+    """SURVEY 8d's stress variant of config 5: 100 000 sequences, ALL of them full-length copies of the 8192-aa
+    query with 5 % point substitutions (scores about 40 000): every sequence saturates plain int16.  The wide
+    form (exact to 65535) and the int16 + flagged int32 re-score path must agree on all 100 000 scores; a
+    seeded sample is compared with the int32 oracle (the whole set is 6.7e12 cells: minutes on the host)."""
+    sc = swg.load_scoring("BLOSUM62")
+    tab = sc.table()
+    lq, n = 8192, 100000
+    q = swg.synth_query(0x5EED0005, lq)
+    flat, off, planted = swg.synth_db(0x5EED0005, n, query=q, fraction=1.0, subst=0.05)
+    assert planted == n and int(off[-1]) == n * lq
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    db = swg.Database(flat, off).upload(ctx)
+    wide, hits, st = ctx.search(db, k=100)
+    assert st["path_bits"] == 16 and st["n_rescored"] == 0 and wide.min() > 32767 and wide.max() < 65535
+    ctx.set_option("wide16", 0)
+    plain, _, st16 = ctx.search(db)
+    ctx.set_option("wide16", 1)
+    assert st16["n_rescored"] == n and np.array_equal(plain, wide)
+    order = np.lexsort((np.arange(n), -wide.astype(np.int64)))[:100]
+    assert hits == [(int(wide[i]), int(i)) for i in order]
+    sample = np.random.default_rng(55).choice(n, size=48, replace=False)
+    s_off = np.arange(len(sample) + 1, dtype=np.uint64) * lq
+    s_flat = np.concatenate([flat[int(off[i]):int(off[i + 1])] for i in sample])
+    assert np.array_equal(orc.score_db(q, s_flat, s_off, tab, -2, -1), wide[sample])
+    db.close()
+
+
+def test_config4_whole_database_on_one_gpu(swg, ctx, orc):
+    """Config 4 as BASELINE names it: ONE 10M-sequence database (3000-aa query), all of it on this GPU (what
+    bench.py's scaling reference runs).  A seeded sample of 16-record batches spread over the whole length
+    range against the REFERENCE's alignment_fill_matrices (oracle/_ref), per entry as test/tests.py:105-133
+    compares; the top-100 against the int32 oracle on the candidates and against the full score vector."""
+    lq, n = 3000, 10000000
+    sc = swg.load_scoring("BLOSUM62")
+    tab = sc.table()
+    q = swg.synth_query(0x5EED0004, lq)
+    sh = swg.synth_db_shard(0x5EED0004, n, 0, 1)           # the generator bench.py --gpus N uses, one shard
+    flat, off = sh["flat"], sh["offsets"]
+    assert np.array_equal(sh["index"], np.arange(n, dtype=np.uint32)) and sh["residues_total"] == int(off[-1])
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    ctx.set_option("autotune", 0)
+    db = swg.Database(flat, off, index=sh["index"], n_total=n).upload(ctx)
+    scores, hits, st = ctx.search(db, k=100)
+    ctx.set_option("autotune", 1)
+    db.close()
+    assert st["path_bits"] == 16 and st["n_rescored"] == 0 and st["cells"] == lq * int(off[-1])
+    # top-100: consistent with the score vector, and every candidate's score equal to the oracle's
+    order = np.lexsort((np.arange(n), -scores.astype(np.int64)))[:100]
+    assert hits == [(int(scores[i]), int(i)) for i in order]
+    c_off = np.zeros(101, dtype=np.uint64)
+    c_off[1:] = np.cumsum([int(off[i + 1] - off[i]) for _, i in hits])
+    c_flat = np.concatenate([flat[int(off[i]):int(off[i + 1])] for _, i in hits])
+    assert np.array_equal(orc.score_db(q, c_flat, c_off, tab, -2, -1), np.array([s for s, _ in hits], dtype=np.int32))
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref was not built (needs the reference sources at build time): candidates checked only")
+    groups = np.unique(np.concatenate([np.random.default_rng(4).choice(n // 16, size=500, replace=False),
+                                       np.arange(0, 40), np.arange(n // 16 - 40, n // 16)]))      # and both ends
+    batches = []
+    for g in groups:
+        o = off[g * 16:g * 16 + 17].astype(np.int64)
+        assert o[1] - o[0] == np.diff(o).max()               # sorted: the first of 16 is the longest (SURVEY A.7-5)
+        b = np.full((int(o[1] - o[0]), 16), 31, dtype=np.int8)
+        for l in range(16):
+            b[:int(o[l + 1] - o[l]), l] = flat[int(o[l]):int(o[l + 1])]
+        batches.append(b)
+    ref, _ = orc.ref_batches(q, batches, tab, -2, -1, threads=int(swg.lib.swg_host_threads()))
+    idx = (groups[:, None] * 16 + np.arange(16)[None, :]).ravel()
+    assert np.array_equal(ref.astype(np.int32).ravel(), scores[idx])
+
+
+def test_many_queries_in_one_pass(swg, ctx, orc):
+    """swg_search_multi: a batch of queries against one resident database in one launch per class must give,
+    query by query, what swg_search gives (and the oracle) -- small database (one query cannot fill the GPU),
+    queries of different lengths in one batch, a long class, more queries than fit one launch, and the
+    batches that fall back to one search after another (a query of several passes; scores that can pass
+    32767; positive gap scores)."""
+    sc = swg.load_scoring("BLOSUM62")
+    tab = sc.table()
+    ctx.set_scoring(sc, -2, -1)
+    _reset_options(ctx)
+    ctx.set_query(swg.synth_query(1, 50))                              # the context's own query must survive
+    flat, off = swg.synth_db(0x5EED0001, 1024)                         # config 1's database
+    db = swg.Database(flat, off).upload(ctx)
+    own, _, _ = ctx.search(db)
+    qs = [swg.synth_query(100 + i, 128) for i in range(64)]
+    got, hits, st = ctx.search_multi(db, qs, k=10)
+    assert st["engine"] == 2 and st["work_queue"] == 1 and st["passes"] == 1 and st["cells"] == 64 * 128 * len(flat)
+    for i in (0, 1, 31, 63):
+        want = orc.score_db(qs[i], flat, off, tab, -2, -1)
+        assert np.array_equal(got[i], want), i
+        assert hits[i] == orc.topk(want, 10)
+    for i, q in enumerate(qs):                                         # every query against the single-query path
+        ctx.set_query(q)
+        one, h1, _ = ctx.search(db, k=10)
+        assert np.array_equal(got[i], one) and hits[i] == h1, i
+    ctx.set_query(swg.synth_query(1, 50))
+    assert np.array_equal(ctx.search(db)[0], own)
+    # mixed lengths (the geometry is the longest query's), 300 queries (two launches of at most 256)
+    rng = np.random.default_rng(9)
+    qs = [swg.synth_query(500 + i, int(rng.integers(1, 200))) for i in range(300)]
+    got, hits, st = ctx.search_multi(db, qs, k=3)
+    for i in (0, 7, 255, 256, 299):
+        want = orc.score_db(qs[i], flat, off, tab, -2, -1)
+        assert np.array_equal(got[i], want) and hits[i] == orc.topk(want, 3), (i, len(qs[i]))
+    db.close()
+    # a larger database with a long tail (bulk and long class side by side), 8 queries
+    flat, off = swg.synth_db(31, 20000)
+    db = swg.Database(flat, off).upload(ctx)
+    qs = [swg.synth_query(900 + i, 367) for i in range(8)]
+    got, _, st = ctx.search_multi(db, qs)
+    for i in (0, 7):
+        assert np.array_equal(got[i], orc.score_db(qs[i], flat, off, tab, -2, -1)), i
+    # fall-backs: several passes, possible saturation, positive gap scores -- same results, one by one
+    flat2, off2 = swg.synth_db(32, 600, max_len=400)
+    db2 = swg.Database(flat2, off2).upload(ctx)
+    long_qs = [swg.synth_query(950 + i, 2500) for i in range(2)] + [swg.synth_query(960, 90)]
+    got, hits, st = ctx.search_multi(db2, long_qs, k=5)
+    for i, q in enumerate(long_qs):
+        want = orc.score_db(q, flat2, off2, tab, -2, -1)
+        assert np.array_equal(got[i], want) and hits[i] == orc.topk(want, 5), i
+    ctx.set_scoring(sc, 1, -2)
+    got, _, st = ctx.search_multi(db2, [long_qs[2], qs[0][:60]])
+    assert st["path_bits"] == 32
+    assert np.array_equal(got[0], orc.score_db(long_qs[2], flat2, off2, tab, 1, -2))
+    assert np.array_equal(got[1], orc.score_db(qs[0][:60], flat2, off2, tab, 1, -2))
+    ctx.set_scoring(sc, -2, -1)
+    with pytest.raises(swg.SwgError):
+        ctx.search_multi(db2, [qs[0], np.zeros(0, np.int8)])            # an empty query is an error, not a crash
+    db.close()
+    db2.close()
+
+
+def test_many_queries_fill_the_gpu_where_one_cannot(swg, ctx):
+    """Config 1's shape (128 aa vs 1024 sequences) is one 5000-row chain per launch: about 80 GCUPS.  64 such
+    queries in one pass must run at least ten times that."""
+    sc = swg.load_scoring("BLOSUM62")
+    ctx.set_scoring(sc, -2, -1)
+    _reset_options(ctx)
+    flat, off = swg.synth_db(0x5EED0001, 1024)
+    db = swg.Database(flat, off).upload(ctx)
+    qs = [swg.synth_query(100 + i, 128) for i in range(64)]
+    ctx.search_multi(db, qs, want_scores=False)                          # warm-up: tokens, code objects
+    best = 0.0
+    for _ in range(3):
+        _, _, st = ctx.search_multi(db, qs, want_scores=False)
+        best = max(best, st["cells"] / (st["fill_ms"] * 1e-3) / 1e9)
+    ctx.set_query(qs[0])
+    ctx.search(db, want_scores=False)
+    _, _, one = ctx.search(db, want_scores=False)
+    single = one["cells"] / (one["fill_ms"] * 1e-3) / 1e9
+    print("one query %.1f GCUPS, 64 queries in one pass %.1f GCUPS" % (single, best))
+    assert best >= 800.0 and best >= 8.0 * single
+    db.close()
