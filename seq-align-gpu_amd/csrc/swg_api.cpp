@@ -138,6 +138,8 @@ extern "C" void swg_destroy(swg_ctx *ctx)
     (void)hipFree(ctx->d_profile[1]);
     (void)hipFree(ctx->d_profile[2]);
     (void)hipFree(ctx->d_profile[3]);
+    (void)hipFree(ctx->d_profile[4]);
+    (void)hipFree(ctx->d_profile[5]);
     (void)hipFree(ctx->d_scratch);
     for (SwgSlot &sl : ctx->slots) {
         for (auto &ev : sl.ev)
@@ -424,9 +426,8 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
 }
 
 static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom, int k_real = 1,
-                               int k_padded = 1)
+                               int k_padded = 1, int chunk_cols = 4)
 {
-    const int chunk_cols = 4;
     const size_t bytes = (size_t)ncols * 32 * elem_size;
     const uint64_t tag = (ctx->epoch << 32) ^ geom;
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
@@ -835,6 +836,165 @@ static int prepare_systolic(swg_ctx *ctx, const swg_db *db, const Plan &pl)
     return ensure_scratch(ctx, need);
 }
 
+// ---------------------------------------------------------------------------
+// int32 with a work queue (swg_diag32q_kernel): non-positive gap scores, one pass
+// ---------------------------------------------------------------------------
+// Occupancy of an int32 work plan.  The int32 profile is twice the int16 one, so LDS, not registers,
+// decides how many workgroups a CU holds: the long class keeps one workgroup of four wavefronts per
+// CU, and the bulk takes the smallest workgroup size W (4, 8, 12 wavefronts sharing one profile) with
+// which the LDS that is left still holds three wavefronts per SIMD, or as many as it can.
+static void q32_occupancy(const swg_ctx *ctx, const SwgDiagWork &wk, int *bulk_W, int *bulk_per_cu)
+{
+    const SwgDiagPlan &pl = wk.plan[0];
+    const SwgKernelInfo info = swg_diag_variant_info(pl.variant);
+    size_t room = 160 * 1024;
+    int cap_waves = std::min(12, info.max_waves);
+    if (wk.n_classes == 2) {
+        room -= std::min(room, swg_diag32q_lds_bytes(wk.plan[1].K, wk.plan[1].G, 4));
+        cap_waves = std::min(cap_waves, info.max_waves - 4);
+    }
+    int best_W = 4, best_n = 1, best_waves = 0;
+    for (int W = 4; W <= info.max_waves; W += 4) {
+        const size_t lds = swg_diag32q_lds_bytes(pl.K, pl.G, W);
+        const int n = std::min<int>((int)(room / lds), cap_waves / W);
+        if (n >= 1 && n * W > best_waves) {
+            best_waves = n * W;
+            best_W = W;
+            best_n = n;
+        }
+    }
+    *bulk_W = best_W;
+    *bulk_per_cu = best_n;
+}
+
+static int q32_class_workgroups(const swg_ctx *ctx, const SwgDiagWork &wk, int c, uint64_t items)
+{
+    const SwgDiagPlan &pl = wk.plan[c];
+    int W = 4, per_cu = 1;
+    if (c == 0) q32_occupancy(ctx, wk, &W, &per_cu);
+    const uint64_t per_wg = (uint64_t)W * (64 / pl.G);
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->n_cu * per_cu, (items + per_wg - 1) / per_wg));
+}
+
+static int q32_class_waves(const swg_ctx *ctx, const SwgDiagWork &wk, int c)
+{
+    int W = 4, per_cu = 1;
+    if (c == 0) q32_occupancy(ctx, wk, &W, &per_cu);
+    return W;
+}
+
+static bool q32_plan_fits(const SwgDiagWork &wk, size_t lq)
+{
+    if (wk.n_classes < 1) return false;
+    for (int c = 0; c < wk.n_classes; ++c) {
+        const SwgDiagPlan &pl = wk.plan[c];
+        if (pl.npass != 1 || (size_t)pl.G * pl.K < lq || swg_diag32q_lds_bytes(pl.K, pl.G, 4) > 160 * 1024) return false;
+    }
+    // both classes run side by side on every CU
+    if (wk.n_classes == 2 && swg_diag32q_lds_bytes(wk.plan[0].K, wk.plan[0].G, 4) + swg_diag32q_lds_bytes(wk.plan[1].K, wk.plan[1].G, 4) >
+                                 160 * 1024)
+        return false;
+    return true;
+}
+
+// Geometry for a list of `n_items` flagged sequences: few of them get 64 lanes each (the shortest
+// chain per row), many the widest single-pass geometry that still fits LDS.
+static bool q32_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_items, SwgDiagWork *wk)
+{
+    const int order[3] = {n_items <= 8u * (uint32_t)ctx->n_cu ? 64 : 16, 32, n_items <= 8u * (uint32_t)ctx->n_cu ? 16 : 64};
+    for (int gi = 0; gi < 3; ++gi) {
+        const int G = order[gi];
+        int best = -1, bestK = 1 << 30;
+        for (int v = 0; v < swg_num_diag_variants(); ++v) {
+            const int K = swg_diag_variant_info(v).K;
+            if ((size_t)G * K >= lq && K < bestK && swg_diag32q_lds_bytes(K, G, 4) <= 160 * 1024) {
+                best = v;
+                bestK = K;
+            }
+        }
+        if (best >= 0) {
+            *wk = SwgDiagWork();
+            wk->n_classes = 1;
+            wk->plan[0].variant = best;
+            wk->plan[0].K = bestK;
+            wk->plan[0].G = G;
+            wk->plan[0].W = 4;
+            wk->plan[0].npass = 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// Launches the int32 work-queue fill: every sequence of the plan's classes (list == NULL), or the
+// device-side list of ranks with one class.  Events as launch_diag.
+static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int go, int ge, const uint32_t *d_list,
+                      const uint32_t *d_list_count, uint32_t list_items, uint32_t *queue_words, bool *two_ends,
+                      bool timing_events = true)
+{
+    hipStream_t s = ctx->stream;
+    const SwgPairTokens &T = db->ptok;
+    const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
+    *two_ends = false;
+    for (int c = 0; c < wk.n_classes; ++c) {
+        const SwgDiagPlan &pl = wk.plan[c];
+        const int kp = swg_q32_padded_cols(pl.K);
+        int rc = ensure_profile_cols(ctx, 4 + c, (uint32_t)(pl.G * kp), 4, (1ull << 33) ^ ((uint64_t)pl.K << 24) ^ (uint64_t)(pl.G * kp),
+                                     pl.K, kp, 2);
+        if (rc != SWG_OK) return rc;
+    }
+    if (timing_events) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
+    if (wk.n_classes == 2) {
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[6], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->cur->ev[6], 0));
+    }
+    for (int c = wk.n_classes - 1; c >= 0; --c) {
+        const SwgDiagPlan &pl = wk.plan[c];
+        SwgDiagQ32Params q;
+        memset(&q, 0, sizeof q);
+        q.tok = T.d_tok;
+        q.pair_off = T.d_pair_off;
+        uint64_t items;
+        if (d_list) {
+            q.list = d_list;
+            q.list_count = d_list_count;
+            items = list_items;
+        } else {
+            q.q_begin = (uint32_t)std::min<uint64_t>(2 * wk.pair_begin[c], n_slots);
+            q.q_end = (uint32_t)std::min<uint64_t>(2 * wk.pair_end[c], n_slots);
+            items = q.q_end - q.q_begin;
+        }
+        q.queue = queue_words + (size_t)c * SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE;
+        q.profile = ctx->d_profile[4 + c];
+        q.scores = db->d_scores;
+        q.seq_limit = (uint32_t)n_slots;
+        q.G = (uint32_t)pl.G;
+        q.go = -go;
+        q.ge = -ge;
+        q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
+        q.simd_ranks = db->d_counters + SWG_RANK_WORD(c);
+        const int wgs = q32_class_workgroups(ctx, wk, c, items);
+        const int W = q32_class_waves(ctx, wk, c);
+        if (c == 0 && !d_list) {
+            const uint64_t blocks = T.pair_blocks_prefix[wk.pair_end[0]] - T.pair_blocks_prefix[wk.pair_begin[0]];
+            const uint64_t groups = (uint64_t)wgs * W * (64 / pl.G);
+            q.prio_blocks = (uint32_t)std::max<uint64_t>(8, (uint64_t)(ctx->opt_prio_share * 0.01 * 2.0 * (double)blocks /
+                                                                       (double)std::max<uint64_t>(1, groups)));
+        } else {
+            q.prio_blocks = c == 1 ? 0u : 0xFFFFFFFFu;
+        }
+        HIP_TRY(ctx, swg_launch_diag32q(pl.variant, W, wgs, q, c == 1 ? ctx->stream2 : s));
+    }
+    if (wk.n_classes == 2) {
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[5], s));
+        HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[7], ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->cur->ev[7], 0));
+        *two_ends = true;
+    }
+    if (timing_events) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
+    return SWG_OK;
+}
+
 // First search of a query length on a database: the cost model ranks the geometries, the few
 // best are timed once on this device (each is a complete, valid fill) and the fastest is kept.
 static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, SwgTuned *tuned)
@@ -1110,7 +1270,33 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // the diagonal engine unless the systolic one is asked for
     const bool use_diag32 = ctx->opt_engine != 1;
     const int npass32 = (int)((lq + 64 * SWG_DIAG32_K - 1) / (64 * SWG_DIAG32_K));
-    if (use_diag32 && (bits == 32 || may_saturate)) {
+    // Non-positive gap scores and a query of one pass: the int32 work-queue kernel (8 instructions per
+    // cell, any lane-group geometry, pairs off the queue) instead of the bin-based one (12 per cell,
+    // 64 lanes x 16 columns whatever the query length).
+    bool q32_ok = fast_ok && use_diag32 && ctx->opt_dynamic != 0 && lq <= 64 * 32;
+    {
+        SwgDiagWork probe; // (LDS holds G * K int32 columns of at most 160 KB: about 1150)
+        q32_ok = q32_ok && q32_list_plan(ctx, lq, 1, &probe);
+    }
+    if (q32_ok && (bits == 32 || may_saturate)) {
+        if ((rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
+        q32_ok = db->ptok.ok;
+    }
+    SwgDiagWork wk32;
+    bool use_q32 = false;
+    if (bits == 32 && q32_ok) {
+        use_q32 = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves, ctx->opt_long_split,
+                                     ctx->opt_workgroups == 0, true, &wk32) > 0 && q32_plan_fits(wk32, lq);
+        if (!use_q32) {
+            // the int16 planner's choice does not fit (LDS holds half as many int32 columns): fewest lanes that do
+            use_q32 = q32_list_plan(ctx, lq, (uint32_t)std::min<size_t>(n_slots, 1u << 30), &wk32);
+            if (use_q32) {
+                wk32.pair_begin[0] = 0;
+                wk32.pair_end[0] = swg_db_pair_count(db);
+            }
+        }
+    }
+    if (use_diag32 && (bits == 32 || may_saturate) && !use_q32) {
         rc = ensure_profile_cols(ctx, 1, (uint32_t)(npass32 * 64 * SWG_DIAG32_K), 4, (1ull << 30) ^ (uint64_t)npass32);
         if (rc != SWG_OK) return rc;
         const size_t per_wave = ((size_t)db->max_nblk * 4 + 4) * 4; // dwords: one uint4 per stream row
@@ -1118,6 +1304,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
     if (use_diag) {
         rc = prepare_diag(ctx, const_cast<swg_db *>(db), wk);
+    } else if (use_q32) {
+        rc = SWG_OK; // profiles are built at the launch
     } else if (!(bits == 32 && use_diag32)) {
         rc = ensure_profile(ctx, main_pl);
     }
@@ -1134,8 +1322,9 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         if ((rc = ensure_scratch(ctx, need)) != SWG_OK) return rc;
     }
 
-    // the systolic engine and the int32 kernels read the bin image (built on the device on first use)
-    if ((!use_diag || may_saturate) && (rc = ensure_bins(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
+    // the systolic engine and the bin-based int32 kernel read the bin image (built on the device on first use)
+    if (((!use_diag && !use_q32) || (may_saturate && !q32_ok)) && (rc = ensure_bins(ctx, const_cast<swg_db *>(db))) != SWG_OK)
+        return rc;
 
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[0], s));
@@ -1152,9 +1341,12 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     p.scratch = ctx->d_scratch;
 
     bool two_ends = false;
-    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
+    if (!use_diag && !use_q32) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
     if (use_diag) {
         if ((rc = launch_diag(ctx, db, wk, go, ge, &two_ends)) != SWG_OK) return rc;
+    } else if (use_q32) {
+        if ((rc = launch_q32(ctx, db, wk32, go, ge, nullptr, nullptr, 0, db->d_counters + SWG_QUEUE_WORD(0), &two_ends)) != SWG_OK)
+            return rc;
     } else if (bits == 32 && use_diag32) {
         p.profile = ctx->d_profile[1];
         p.queue = db->d_counters + 0;
@@ -1184,7 +1376,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb;
         HIP_TRY(ctx, swg_launch_fill(bits, main_pl.variant, main_pl.W, main_pl.workgroups, p, s));
     }
-    if (!use_diag) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
+    if (!use_diag && !use_q32) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
     if (may_saturate) {
         HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, wide ? 65535 : 32767, db->d_list,
                                                   db->d_counters + 1, s));
@@ -1201,7 +1393,17 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             uint32_t n_sat = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&n_sat, db->d_counters + 1, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, spin_sync(ctx, s));
-            if (n_sat > 0) {
+            SwgDiagWork wkl;
+            if (n_sat > 0 && q32_ok && q32_list_plan(ctx, lq, n_sat, &wkl)) {
+                // (fresh queue counters and rank table: the fill's are spent; no events of its own: the
+                // re-score is timed as ev[2] .. ev[3] like the other re-score forms)
+                HIP_TRY(ctx, hipMemsetAsync(db->d_counters + SWG_QUEUE_WORD(0), 0,
+                                            (size_t)(SWG_COUNTER_BYTES - SWG_QUEUE_WORD(0) * 4u), s));
+                bool two = false;
+                rc = launch_q32(ctx, db, wkl, go, ge, db->d_list, db->d_counters + 1, n_sat, db->d_counters + SWG_QUEUE_WORD(0), &two,
+                                false);
+                if (rc != SWG_OK) return rc;
+            } else if (n_sat > 0) {
                 int W = (int)((n_sat + (uint32_t)ctx->n_cu - 1) / (uint32_t)ctx->n_cu);
                 W = std::min(16, std::max(4, (W + 3) / 4 * 4));
                 const int wgs = (int)std::min<uint32_t>((uint32_t)ctx->n_cu, (n_sat + W - 1) / W);
@@ -1240,6 +1442,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     S->may_saturate = may_saturate;
     S->use_diag = use_diag;
     S->use_diag32 = use_diag32;
+    S->use_q32 = use_q32;
+    S->wk32 = wk32;
     S->npass32 = npass32;
     S->wk = wk;
     S->main_K = main_pl.K;
@@ -1325,6 +1529,24 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
             st.long_cols_per_lane = lp.K;
             st.long_streams = (int32_t)diag_class_streams(ctx, db, wk, 1);
             st.cells_padded += 2ull * lp.npass * lp.G * lp.K * diag_class_blocks(ctx, db, wk, 1) * 4ull;
+        }
+    } else if (S->use_q32) {
+        const SwgDiagWork &w32 = S->wk32;
+        st.engine = 2;
+        st.work_queue = 1;
+        st.cols_per_wave = w32.plan[0].K;
+        st.group_lanes = w32.plan[0].G;
+        st.waves = q32_class_waves(ctx, w32, 0);
+        st.passes = 1;
+        const uint64_t items0 = 2 * (w32.pair_end[0] - w32.pair_begin[0]);
+        st.workgroups = q32_class_workgroups(ctx, w32, 0, items0);
+        st.streams = st.workgroups * st.waves * (64 / w32.plan[0].G);
+        for (int c = 0; c < w32.n_classes; ++c)
+            st.cells_padded += 2ull * w32.plan[c].G * w32.plan[c].K *
+                               (uint64_t)(db->ptok.pair_blocks_prefix[w32.pair_end[c]] - db->ptok.pair_blocks_prefix[w32.pair_begin[c]]) * 4ull;
+        if (w32.n_classes == 2) {
+            st.long_pairs = (int32_t)(w32.pair_end[1] - w32.pair_begin[1]);
+            st.long_cols_per_lane = w32.plan[1].K;
         }
     } else if (bits == 32 && use_diag32) {
         st.engine = 2;

@@ -156,7 +156,8 @@ struct SwgSlot {
     swg_db::Bufs bufs; // the output buffers this search writes
     size_t k = 0, first_chunk = 0;
     bool want_scores = false, dev_topk = false, need_scores = false, two_ends = false, may_saturate = false;
-    bool use_diag = false, use_diag32 = false;
+    bool use_diag = false, use_diag32 = false, use_q32 = false;
+    SwgDiagWork wk32; // int32 work-queue fill of the whole database
     int bits = 0, npass32 = 0, main_K = 0, main_W = 0, main_npass = 0, main_wgs = 0;
     SwgDiagWork wk;
     swg_stats st;
@@ -184,10 +185,12 @@ struct swg_ctx {
     int8_t *d_sub = nullptr;
     int8_t *d_query = nullptr;
     size_t d_query_cap = 0;
-    // [0] int16, [1] int32, [2] int16 in 2-column chunks, [3] int16 in per-lane slices of an odd K
-    uint8_t *d_profile[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t d_profile_cap[4] = {0, 0, 0, 0};
-    uint64_t profile_tag[4] = {0, 0, 0, 0}; // identifies (query, scoring, geometry) currently built
+    // [0] int16, whole 4-column chunks per lane; [1] int32 (bin-based kernels); [2] / [3] int16 in per-lane
+    // slices padded to whole chunks, long class / bulk; [4] / [5] int32 in 2-column chunks (work-queue
+    // int32 kernel), bulk or list / long class
+    uint8_t *d_profile[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t d_profile_cap[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t profile_tag[6] = {0, 0, 0, 0, 0, 0}; // identifies (query, scoring, geometry) currently built
     uint64_t epoch = 1;               // bumps whenever scoring or query change
     uint32_t *d_scratch = nullptr;
     size_t d_scratch_cap = 0; // dwords

@@ -81,6 +81,29 @@ struct SwgDiagDynParams {
     uint32_t queue_stride;
 };
 
+// The int32 fill with a work queue (swg_diag32q_kernel): items are sequences (sorted ranks), either
+// the ranks [q_begin, q_end) or the entries of a device-side list.
+struct SwgDiagQ32Params {
+    const uint4 *tok;           // pair-major token blocks
+    const uint32_t *pair_off;   // [n_pairs+1]
+    uint32_t q_begin, q_end;    // ranks to score (list == NULL)
+    const uint32_t *list;       // or: ranks to score ...
+    const uint32_t *list_count; // ... and how many (device side)
+    uint32_t *queue;            // SWG_DYN_SHARDS counters, zero before the launch
+    const uint8_t *profile;     // [G lanes][KP/2 chunks][32][2] int32
+    int32_t *scores;            // by sorted rank
+    uint32_t seq_limit;         // ranks the score array has room for
+    uint32_t G;
+    int32_t go, ge;             // |gap_open+gap_extend|, |gap_extend|
+    uint32_t prio_blocks;       // a wavefront feeding a sequence of >= this many blocks runs at raised priority
+    uint32_t *simd_ranks;       // [SWG_DYN_SIMD_SLOTS] zero before the launch
+    uint32_t turn_levels;
+};
+int swg_q32_padded_cols(int K);
+size_t swg_diag32q_lds_bytes(int K, int G, int W);
+// variant: index into the diagonal variants (swg_diag_variant_info gives its K)
+hipError_t swg_launch_diag32q(int variant, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream);
+
 struct SwgKernelInfo {
     int bits;      // 16 or 32
     int K;         // query columns per wavefront

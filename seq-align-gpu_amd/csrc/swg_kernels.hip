@@ -1016,6 +1016,248 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
 }
 
 // ---------------------------------------------------------------------------
+// The int32 fill with a work queue: G lanes share ONE sequence, scores beyond 16 bits
+// ---------------------------------------------------------------------------
+// For everything the packed int16 form cannot hold -- sequences whose 16-bit score saturated,
+// force_bits = 32 -- when the gap scores are non-positive and the query fits one pass (G*K columns).
+// Same skeleton as swg_diag_dyn_kernel: persistent wavefronts, lane groups of 16 / 32 / 64 lanes
+// sweeping an anti-diagonal, work items off sharded counters, the token stream of the PAIR the
+// sequence belongs to (the leader lane picks the pair's X or Y residue byte), scores collected by an
+// LDS atomic maximum on the last row.  An item is one sequence (sorted rank): either every rank of a
+// range, or the entries of a device-side list (the saturated ones).
+//
+// Cells: the same algebra as the packed form, in int32, with three-operand maxima doing the floors:
+//     a = max3(G[k], A[k] - e, 0)    b = max3(gl, bl - e, 0)    m = max3(md + s, a, b)    G' = m - g
+// (G = M - |go| unfloored: max3's zero does it) = 8 instructions per cell against 12 for the
+// reference's recurrence term by term (which stays the path for positive gap scores:
+// swg_diag32_kernel).  Profile: [col/2][32 residues][2] int32 -- a residue's two columns are 8 bytes,
+// so the token's residue byte is the LDS offset as it stands, like the int16 kernels.
+template <int K> struct CellsQ32 {
+    static constexpr int KP = (K + 1) / 2 * 2;
+    static constexpr int CHUNK = 32 * 2 * 4; // 256 bytes: 32 residues x 2 columns x int32
+    int M[K], G[K], A[K];
+    int best, mdl;
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) M[k] = G[k] = A[k] = 0;
+        best = 0;
+        mdl = 0;
+    }
+
+    // em / eb: M and B of the column left of this lane's strip in this row; go / ge: gap magnitudes
+    template <bool FENCED = false> DEVINL int2 row(const uint8_t *prof, uint32_t ax, int em, int eb, int go, int ge)
+    {
+        constexpr int NCH = KP / 2;
+        int md = mdl;
+        int gl = em - go;
+        int bl = eb;
+        int2 nx = *reinterpret_cast<const int2 *>(prof + ax);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int2 w = nx;
+            if (c + 1 < NCH) nx = *reinterpret_cast<const int2 *>(prof + ax + (c + 1) * CHUNK);
+            const int s[2] = {w.x, w.y};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 2 * c + u;
+                if (k >= K) break; // unused tail of an odd K's last chunk
+                const int t = md + s[u];
+                md = M[k];
+                const int a = imax3(G[k], A[k] - ge, 0);
+                const int b = imax3(gl, bl - ge, 0);
+                const int m = imax3(t, a, b);
+                M[k] = m;
+                A[k] = a;
+                gl = G[k] = m - go;
+                bl = b;
+                best = imax(best, m);
+            }
+            if (FENCED && (c & 1) && c + 1 < NCH) __builtin_amdgcn_sched_barrier(0);
+        }
+        mdl = em;
+        return make_int2(M[K - 1], bl);
+    }
+};
+
+#define SWG_Q32_RESET_GAP (1 << 29) // gap magnitude on reset rows: one such row zeroes A, G and B, two zero M
+
+template <int K, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // int32 query profile, then the group records
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int G = (int)p.G;
+    const int gshift = G == 16 ? 4 : G == 32 ? 5 : 6;
+    const int g = lane & (G - 1);
+    const bool leader = g == 0, tail = g == G - 1;
+    const uint32_t base = (uint32_t)g * (CellsQ32<K>::KP / 2) * CellsQ32<K>::CHUNK;
+    const uint32_t slice = (uint32_t)G * CellsQ32<K>::KP * 128u;
+    auto record = [&]() -> uint32_t * {
+        const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        return reinterpret_cast<uint32_t *>(smem + slice) + (((uint32_t)w << (6 - gshift)) + (l >> gshift)) * SWG_DYN_STATE;
+    };
+    for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
+        *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(p.profile + o);
+    {
+        uint32_t *st = record();
+        if (g < 4) st[g] = 0u; // every group is due at block 0
+        for (uint32_t i = (uint32_t)g; i < 2u * SWG_DYN_RING; i += (uint32_t)G) st[SWG_DYN_MAXES + i] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n_items = p.list_count ? *p.list_count : p.q_end - p.q_begin;
+
+    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+    CellsQ32<K> cells;
+    cells.reset();
+    uint32_t tok = 0u;
+    int m_out = 0, b_out = 0;
+    int go_v = (int)p.go, ge_v = (int)p.ge;
+    uint32_t nlast = 0u;
+    // v_perm selector of the leader: residue byte of X (.. 00) or Y (.. 01), zero, flags byte, zero.  It
+    // belongs to the sequence whose tokens are being LOADED; the blocks in flight keep the selector they
+    // were loaded under (pick_nxt, pick_cur), or the last rows of a sequence would be read with its
+    // successor's.
+    uint32_t pick = 0x0C020C00u, pick_nxt = 0x0C020C00u, pick_cur = 0x0C020C00u;
+    uint4 cur = none, nxt = none;
+    uint32_t bi = SWG_DYN_NONE;
+    uint32_t blocks = 0u, next_event = 0u, drain = 0u;
+    bool hot = false;
+    uint32_t rank;
+    {
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((11 << 11) | (4 << 6) | 4);
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        const uint32_t simd = (((hw >> 4) << 2) | (hw & 3u) | (xcc << 10)) & (SWG_DYN_SIMD_SLOTS - 1u);
+        uint32_t r = 0u;
+        if (lane == 0) r = atomicAdd(p.simd_ranks + simd, 1u);
+        rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    }
+    auto take_turn = [&]() {
+        const uint32_t x = ((uint32_t)(wall_clock64() >> SWG_DYN_TURN_SHIFT) + rank) & 0xFFFFu;
+        const uint32_t turn = p.turn_levels == 4u ? (x & 3u) : x - 3u * ((x * 0xAAABu) >> 17);
+        if (turn == 0u) __builtin_amdgcn_s_setprio(0);
+        else if (turn == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (turn == 2u) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    };
+
+    for (;;) {
+        if (blocks == next_event) {
+            // some sequence has run out (or this is the start): its leader takes the next one
+            __builtin_amdgcn_s_setprio(3);
+            uint32_t *st = record();
+            uint32_t end_at = st[0];
+            uint32_t fl = st[1];
+            if (leader && end_at == blocks) {
+                uint32_t tried = fl >> 8;
+                uint32_t item = SWG_DYN_NONE;
+                while (tried < SWG_DYN_SHARDS) {
+                    const uint32_t shard = (blockIdx.x + tried) & (SWG_DYN_SHARDS - 1u);
+                    const uint32_t cand = shard + SWG_DYN_SHARDS * atomicAdd(p.queue + shard * SWG_DYN_SHARD_STRIDE, 1u);
+                    if (cand < n_items) {
+                        item = cand;
+                        break;
+                    }
+                    ++tried;
+                }
+                fl = tried << 8;
+                uint32_t seq = SWG_DYN_NONE;
+                if (item != SWG_DYN_NONE) seq = p.list ? p.list[item] : p.q_begin + item;
+                if (seq != SWG_DYN_NONE && seq < p.seq_limit) {
+                    const uint32_t pr = seq >> 1;
+                    bi = p.pair_off[pr];
+                    const uint32_t len = p.pair_off[pr + 1u] - bi;
+                    end_at = blocks + len;
+                    pick = 0x0C020C00u | (seq & 1u);
+                    const uint32_t pushed = st[2];
+                    st[SWG_DYN_RING + (pushed & (SWG_DYN_RING - 1u))] = seq;
+                    st[2] = pushed + 1u;
+                    if (len >= p.prio_blocks) fl |= SWG_DYN_HOT;
+                } else {
+                    end_at = SWG_DYN_NONE;
+                    bi = SWG_DYN_NONE;
+                }
+                st[0] = end_at;
+                st[1] = fl;
+            }
+            next_event = SWG_DYN_NONE;
+            for (int i = 0; i < 64; i += G)
+                next_event = min(next_event, (uint32_t)__builtin_amdgcn_readlane((int)end_at, i));
+            hot = __builtin_amdgcn_ballot_w64(leader && end_at != SWG_DYN_NONE && (fl & SWG_DYN_HOT) != 0u) != 0ull;
+            if (!hot) take_turn();
+        }
+        if (next_event == SWG_DYN_NONE) {
+            if (drain >= (uint32_t)G + 12u) break;
+            drain += 4u;
+        }
+        cur = nxt;
+        pick_cur = pick_nxt;
+        nxt = none;
+        if (bi != SWG_DYN_NONE) {
+            nxt = p.tok[bi];
+            pick_nxt = pick;
+            ++bi;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // the leader's token of this row: the residue byte of ITS sequence of the pair, and the flags
+            const uint32_t raw = block_row(cur, r);
+            const uint32_t fresh = __builtin_amdgcn_perm(raw, raw, pick_cur);
+            int em, eb;
+            const int Gs = opaque_uniform(G);
+            if (Gs == 16) {
+                tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
+                em = (int)dpp_zero<DPP_ROW_SHR1>((uint32_t)m_out);
+                eb = (int)dpp_zero<DPP_ROW_SHR1>((uint32_t)b_out);
+            } else {
+                const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
+                const uint32_t u1 = dpp_zero<DPP_WAVE_SHR1>((uint32_t)m_out);
+                const uint32_t u2 = dpp_zero<DPP_WAVE_SHR1>((uint32_t)b_out);
+                if (Gs == 32) { // lane 32 starts a group too
+                    tok = leader ? fresh : u0;
+                    em = leader ? 0 : (int)u1;
+                    eb = leader ? 0 : (int)u2;
+                } else {
+                    tok = u0;
+                    em = (int)u1;
+                    eb = (int)u2;
+                }
+            }
+            const bool special = __builtin_amdgcn_ballot_w64(tok > 0xFFFFu) != 0ull;
+            if (special) {
+                uint32_t fm = 0u - ((tok >> 16) & 1u);
+                asm volatile("" : "+v"(fm)); // (keeps this a branch)
+                cells.best &= (int)~fm;
+                go_v = (int)(((uint32_t)go_v & ~fm) | (SWG_Q32_RESET_GAP & fm));
+                ge_v = (int)(((uint32_t)ge_v & ~fm) | (SWG_Q32_RESET_GAP & fm));
+            }
+            const int2 e = cells.template row<(K > 12)>(smem, base + (tok & 0xFFu), em, eb, go_v, ge_v);
+            if (special) {
+                go_v = (int)p.go;
+                ge_v = (int)p.ge;
+                if (tok & SWG_TOK_LAST) {
+                    uint32_t *st = record();
+                    const uint32_t at = nlast & (SWG_DYN_RING - 1u);
+                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + at, (uint32_t)cells.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (tail) {
+                        const uint32_t seq = st[SWG_DYN_RING + at];
+                        const uint32_t sc = __hip_atomic_exchange(st + SWG_DYN_MAXES + at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (seq < p.seq_limit) p.scores[seq] = (int)sc;
+                    }
+                    ++nlast;
+                }
+            }
+            m_out = e.x;
+            b_out = e.y;
+        }
+        ++blocks;
+        if (!hot) take_turn();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------
 __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
@@ -1485,6 +1727,48 @@ const DiagVariant *diag_variants(int *n)
     return v;
 }
 } // namespace
+
+namespace {
+template <int K, int MAXW> void (*q32_kernel())(const SwgDiagQ32Params) { return swg_diag32q_kernel<K, MAXW>; }
+typedef void (*Q32Kernel)(const SwgDiagQ32Params);
+// one instantiation per K of the diagonal variants (same order: the variant index is shared)
+const Q32Kernel *q32_kernels()
+{
+    static const Q32Kernel v[] = {
+        q32_kernel<24, 16>(), q32_kernel<12, 16>(), q32_kernel<8, 16>(), q32_kernel<16, 16>(), q32_kernel<32, 12>(),
+        q32_kernel<6, 16>(),  q32_kernel<10, 16>(), q32_kernel<20, 16>(), q32_kernel<28, 12>(), q32_kernel<4, 16>(),
+        q32_kernel<14, 16>(), q32_kernel<18, 16>(), q32_kernel<22, 16>(), q32_kernel<2, 16>(),
+        q32_kernel<23, 16>(), q32_kernel<21, 16>(), q32_kernel<19, 16>(), q32_kernel<17, 16>(), q32_kernel<15, 16>(),
+        q32_kernel<13, 16>(), q32_kernel<11, 16>(), q32_kernel<9, 16>(), q32_kernel<7, 16>(), q32_kernel<31, 12>(),
+        q32_kernel<29, 12>(), q32_kernel<27, 12>(), q32_kernel<25, 12>(), q32_kernel<30, 12>(), q32_kernel<26, 12>(),
+        q32_kernel<5, 16>(), q32_kernel<3, 16>(),
+    };
+    return v;
+}
+} // namespace
+
+int swg_q32_padded_cols(int K) { return (K + 1) / 2 * 2; }
+
+size_t swg_diag32q_lds_bytes(int K, int G, int W)
+{
+    return (size_t)G * swg_q32_padded_cols(K) * 128u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
+}
+
+hipError_t swg_launch_diag32q(int variant, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream)
+{
+    int n;
+    const DiagVariant *v = diag_variants(&n);
+    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
+        (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
+        return hipErrorInvalidValue;
+    const size_t lds = swg_diag32q_lds_bytes(v[variant].info.K, (int)p.G, W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = q32_kernels()[variant];
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
+    return hipGetLastError();
+}
 
 int swg_num_diag_variants()
 {
