@@ -330,7 +330,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
                 "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
                 "streams": last["streams"], "long_pairs": last["long_pairs"],
                 "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],
-                "work_queue": bool(last["work_queue"]),
+                "work_queue": bool(last["work_queue"]), "classes_overlapped": last["classes_overlapped"],
                 "cells_padded_over_real": round(last["cells_padded"] / max(1, last["cells"]), 4),
             },
             "roofline": {

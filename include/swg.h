@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SWG_ABI_VERSION 1
+#define SWG_ABI_VERSION 2
 
 typedef enum swg_status {
     SWG_OK = 0,
@@ -82,6 +82,14 @@ typedef struct swg_stats {
     int32_t long_cols_per_lane;
     int32_t long_streams;
     int32_t work_queue;     /* diagonal engine: 1 = pairs handed out by the device-side work queue */
+    /* Two classes (bulk and long pairs) are launched on two HIP streams and are MEANT to run side by
+     * side on every CU (the plan's cost model assumes it).  Whether they did is measured, not assumed:
+     * each kernel stamps the wall clock when its first wavefront starts and when its last one ends.
+     * 1 = the long class started before a tenth of the bulk's run had passed; 0 = it did not (streams
+     * sharing a hardware queue -- a host program with many HIP streams should raise GPU_MAX_HW_QUEUES --
+     * or its workgroups found no room); -1 = a single class, nothing to overlap. */
+    int32_t classes_overlapped;
+    int32_t reserved_;
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */

@@ -74,11 +74,12 @@ class Stats(C.Structure):
         ("cols_per_wave", C.c_int32), ("waves", C.c_int32), ("passes", C.c_int32),
         ("workgroups", C.c_int32), ("engine", C.c_int32), ("group_lanes", C.c_int32),
         ("streams", C.c_int32), ("long_pairs", C.c_int32), ("long_cols_per_lane", C.c_int32),
-        ("long_streams", C.c_int32), ("work_queue", C.c_int32),
+        ("long_streams", C.c_int32), ("work_queue", C.c_int32), ("classes_overlapped", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
 
 
 class Batch16(C.Structure):

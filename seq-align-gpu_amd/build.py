@@ -60,6 +60,73 @@ def _headers():
     return hs
 
 
+OBJDUMP = os.path.join(ROCM, "lib", "llvm", "bin", "llvm-objdump")
+ISA_STAMP = os.path.join(OBJ, "isa_checked")
+
+
+def verify_isa(lib=LIB):
+    """The int16 fill kernels must read their profile with ds_read_b64 and never with ds_read2_b64 (which is
+    what DEVICE_FLAGS is for).  A compiler that drops or renames the feature would fuse the reads silently and
+    halve the LDS rate: this looks at the built code object instead of trusting the flag.  Returns
+    {kernel family: (ds_read_b64 count, ds_read2_b64 count)}; raises if a family has fused reads or none."""
+    import glob
+    import re
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    try:
+        copy = os.path.join(tmp, "libswg.so")
+        shutil.copy(lib, copy)
+        subprocess.run([OBJDUMP, "--offloading", copy], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, cwd=tmp)
+        counts = {}
+        fam = None
+        for co in sorted(glob.glob(copy + ".*gfx950*")):
+            out = subprocess.run([OBJDUMP, "-d", co], stdout=subprocess.PIPE, text=True, check=True).stdout
+            for line in out.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+                if m:
+                    name = m.group(1)
+                    fam = next((f for f in ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_diag32q_kernel")
+                                if f in name), None)
+                    continue
+                if fam and "ds_read" in line:
+                    a, b = counts.get(fam, (0, 0))
+                    counts[fam] = (a + ("ds_read_b64" in line), b + ("ds_read2_b64" in line))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for fam in ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_diag32q_kernel"):
+        a, b = counts.get(fam, (0, 0))
+        if a == 0 or b != 0:
+            raise RuntimeError("%s: %d ds_read_b64 and %d ds_read2_b64 in the built kernels -- the load/store optimizer "
+                               "switch (DEVICE_FLAGS) no longer keeps the profile reads unfused" % (fam, a, b))
+    return counts
+
+
+def _lib_digest():
+    import hashlib
+    h = hashlib.sha1()
+    with open(LIB, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def ensure_isa_checked(verbose=True):
+    """verify_isa() once per built library (a minute of disassembly): the stamp holds the library's digest,
+    so a copy of the tree (the GPU box gets one) does not check again."""
+    digest = _lib_digest()
+    try:
+        if open(ISA_STAMP).read().split()[0] == digest:
+            return False
+    except (OSError, IndexError):
+        pass
+    counts = verify_isa()
+    if verbose:
+        print("[isa]", ", ".join("%s: %d ds_read_b64, no ds_read2_b64" % (k, v[0]) for k, v in sorted(counts.items())))
+    os.makedirs(OBJ, exist_ok=True)
+    open(ISA_STAMP, "w").write(digest + "\n" + repr(counts) + "\n")
+    return True
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
@@ -96,6 +163,7 @@ def build(force=False, verbose=True):
             print("[link] libswg.so")
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
              + ["-lgomp", "-lz", "-lm", "-ldl"])
+    ensure_isa_checked(verbose)
     cli_srcs = [os.path.join(HOST, s) for s in CLI_SOURCES if os.path.exists(os.path.join(HOST, s))]
     if cli_srcs and (force or _stale(CLI, cli_srcs + [LIB] + hdrs)):
         if verbose:

@@ -147,6 +147,11 @@ extern "C" void swg_destroy(swg_ctx *ctx)
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         (void)hipHostFree(sl.h_cand);
         (void)hipHostFree(sl.h_counters);
+        (void)hipHostFree(sl.h_scores);
+    }
+    for (int i = 0; i < 4; ++i) {
+        (void)hipHostFree(ctx->h_query_stage[i]);
+        if (ctx->ev_query_stage[i]) (void)hipEventDestroy(ctx->ev_query_stage[i]);
     }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
@@ -240,9 +245,26 @@ extern "C" int swg_set_query(swg_ctx *ctx, const int8_t *idx, size_t lq)
     }
     // No wait here: the copy and the profile build that consumes it are ordered on the context's
     // stream behind any search still in flight, so a caller can stream queries against a resident
-    // database (set_query, search_begin, set_query, search_begin, search_end, ...).
+    // database (set_query, search_begin, set_query, search_begin, search_end, ...).  The copy reads a
+    // pinned staging buffer of its own (four in rotation, each guarded by an event): the host copy
+    // ctx->query is rewritten by the next call while this one's transfer may still be queued.
     ctx->query.assign(idx, idx + lq);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_query, ctx->query.data(), lq, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int b = ctx->query_stage_next;
+        ctx->query_stage_next = (b + 1) % 4;
+        if (!ctx->ev_query_stage[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_query_stage[b], hipEventDisableTiming));
+        else HIP_TRY(ctx, hipEventSynchronize(ctx->ev_query_stage[b])); // (four transfers ago: long done)
+        if (lq > ctx->h_query_stage_cap[b]) {
+            (void)hipHostFree(ctx->h_query_stage[b]);
+            ctx->h_query_stage[b] = nullptr;
+            ctx->h_query_stage_cap[b] = 0;
+            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_query_stage[b]), lq, hipHostMallocDefault));
+            ctx->h_query_stage_cap[b] = lq;
+        }
+        memcpy(ctx->h_query_stage[b], idx, lq);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_query, ctx->h_query_stage[b], lq, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_query_stage[b], ctx->stream));
+    }
     ctx->epoch++;
     return SWG_OK;
 }
@@ -715,6 +737,8 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
             q.simd_ranks = db->d_counters + SWG_RANK_WORD(c);
             q.trace = d_trace[c];
+            // start / end wall-clock stamps of single-pass launches: words 8..15 of the counters
+            q.stamps = pl.npass == 1 ? reinterpret_cast<unsigned long long *>(db->d_counters + 8 + 4 * c) : nullptr;
             const bool edges = pl.npass > 1 || pl.wide != 0;
             const size_t slice = (size_t)pl.G * swg_diag_padded_cols(pl.K) * 64;
             hipStream_t qs = c == 1 ? ctx->stream2 : s;
@@ -1146,6 +1170,19 @@ extern "C" size_t swg_topk_merge_keys(const uint64_t *keys, size_t n, size_t k, 
     return m;
 }
 
+// Pinned landing buffer of a slot's score read-out (a pageable destination would make the "async"
+// copy block the host behind everything queued before it).
+static int slot_scores(swg_ctx *ctx, SwgSlot *S, size_t n)
+{
+    if (n <= S->h_scores_cap) return SWG_OK;
+    (void)hipHostFree(S->h_scores);
+    S->h_scores = nullptr;
+    S->h_scores_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&S->h_scores), std::max<size_t>(n, 64) * sizeof(int32_t), hipHostMallocDefault));
+    S->h_scores_cap = std::max<size_t>(n, 64);
+    return SWG_OK;
+}
+
 // Queues one whole search on the context's stream and returns without waiting (except on the
 // first search of a query length, which tunes the geometry, and when int16 scores may
 // saturate, where the number of flagged sequences is read back to size the re-score).
@@ -1167,7 +1204,6 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     S->db = db;
     S->k = k;
     S->want_scores = want_scores;
-    S->h_scores.clear();
     swg_stats &st = S->st;
     memset(&st, 0, sizeof st);
     const size_t lq = ctx->query.size();
@@ -1207,8 +1243,10 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     Plan main_pl, re_pl;
     memset(&main_pl, 0, sizeof main_pl);
     memset(&re_pl, 0, sizeof re_pl);
+    // (the systolic plan: only the systolic engine needs it to exist -- a cols_per_wave meant for the
+    // diagonal engine has no systolic instantiation, and with engine != 1 both widths run on lane groups)
     int rc = make_plan(ctx, bits, bits == 16 ? n_bins : n_bins * 2, &main_pl);
-    if (rc != SWG_OK && !(bits == 16 && ctx->opt_engine != 1)) return rc;
+    if (rc != SWG_OK && ctx->opt_engine == 1) return rc;
     // int16: the diagonal engine unless the systolic one is asked for
     SwgDiagWork wk;
     bool use_diag = false, tuned_systolic = false;
@@ -1453,10 +1491,10 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     if (dev_topk)
         HIP_TRY(ctx, hipMemcpyAsync(S->h_cand, db->d_keys, S->first_chunk * 8, hipMemcpyDeviceToHost, s));
     if (S->need_scores) {
-        S->h_scores.resize(n_slots);
-        HIP_TRY(ctx, hipMemcpyAsync(S->h_scores.data(), db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
+        if ((rc = slot_scores(ctx, S, n_slots)) != SWG_OK) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(S->h_scores, db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(S->h_counters, db->d_counters, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_counters, db->d_counters, 64, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(S->ev_done, s));
     return SWG_OK;
 }
@@ -1494,12 +1532,12 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     const SwgDiagPlan &dpl = wk.plan[0];
     uint32_t *h_counters = S->h_counters;
     uint64_t *h_cand = S->h_cand;
-    std::vector<int32_t> &h_scores = S->h_scores;
+    int32_t *&h_scores = S->h_scores;
     int rc = SWG_OK;
     bool cand_ok = dev_topk && h_counters[5] == 0 && h_counters[3] <= SWG_TOPK_CAND_CAP;
     if (dev_topk && !cand_ok) { // threshold beyond the histogram or too many ties: select on the host
-        h_scores.resize(n_slots);
-        HIP_TRY(ctx, hipMemcpyAsync(h_scores.data(), S->bufs.d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
+        if ((rc = slot_scores(ctx, S, n_slots)) != SWG_OK) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(h_scores, S->bufs.d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, spin_sync(ctx, s));
     }
 
@@ -1513,6 +1551,16 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     const double topk_dev_ms = ms;
     st.n_rescored = h_counters[1];
     st.path_bits = bits;
+    st.classes_overlapped = -1;
+    if (use_diag && wk.n_classes == 2 && wk.plan[0].npass == 1 && wk.plan[1].npass == 1) {
+        // did the two classes run side by side?  (stamps: complement of the earliest start, latest end)
+        unsigned long long t[4];
+        memcpy(t, h_counters + 8, sizeof t);
+        if (t[0] && t[1] && t[2] && t[3]) {
+            const unsigned long long bulk_start = ~t[0], bulk_end = t[1], long_start = ~t[2];
+            st.classes_overlapped = (bulk_end > bulk_start && long_start < bulk_start + (bulk_end - bulk_start) / 10) ? 1 : 0;
+        }
+    }
     if (use_diag) {
         st.engine = 2;
         st.cols_per_wave = dpl.K;

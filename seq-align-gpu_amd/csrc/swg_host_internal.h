@@ -163,7 +163,8 @@ struct SwgSlot {
     swg_stats st;
     uint64_t *h_cand = nullptr;     // pinned, SWG_TOPK_CAND_CAP keys
     uint32_t *h_counters = nullptr; // pinned, 8 words
-    std::vector<int32_t> h_scores;
+    int32_t *h_scores = nullptr;    // pinned landing buffer of the score read-out, grown on demand
+    size_t h_scores_cap = 0;        // entries
 };
 
 struct swg_ctx {
@@ -177,8 +178,14 @@ struct swg_ctx {
     bool have_scoring = false;
     int8_t sub[32][32];
     int gap_open = 0, gap_extend = 0;
-    // query
+    // query: the host copy, and pinned staging buffers for the copy to the device (a buffer is not
+    // written again before the copy that reads it has completed, so set_query / search_begin can be
+    // streamed without a wait)
     std::vector<int8_t> query;
+    int8_t *h_query_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t h_query_stage_cap[4] = {0, 0, 0, 0};
+    hipEvent_t ev_query_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    int query_stage_next = 0;
     // options
     long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 0, opt_wide = 1, opt_side_readout = 1;
     // device state

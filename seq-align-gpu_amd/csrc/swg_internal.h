@@ -79,6 +79,9 @@ struct SwgDiagDynParams {
     // y * score_stride (entries).  All zero for a single query.
     uint64_t profile_stride, score_stride;
     uint32_t queue_stride;
+    // diagnostics that cost nothing: [0] wall clock when the first wavefront of the launch started
+    // (atomic min), [1] when the last one ended (atomic max); zero-initialised = not run.  Null: none.
+    unsigned long long *stamps;
 };
 
 // The int32 fill with a work queue (swg_diag32q_kernel): items are sequences (sorted ranks), either

@@ -777,6 +777,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         return reinterpret_cast<uint32_t *>(smem + slice) + (((uint32_t)w << (6 - gshift)) + (l >> gshift)) * SWG_DYN_STATE;
     };
     const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
+    if (p.stamps && lane == 0) atomicMax(p.stamps, ~(unsigned long long)wall_clock64()); // earliest start, as the maximum of the complements (0 = not run)
     // several queries in one launch: row y of the grid works for query y (its profile, its queue, its scores)
     const uint8_t *profile = p.profile + (size_t)blockIdx.y * p.profile_stride;
     uint32_t *const queue = p.queue + (size_t)blockIdx.y * p.queue_stride;
@@ -1005,6 +1006,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         ++blocks;
         if (!hot && (blocks & (SWG_DYN_TURN_EVERY - 1u)) == 0u) take_turn();
     }
+    if (p.stamps && lane == 0) atomicMax(p.stamps + 1, (unsigned long long)wall_clock64()); // latest end
     if (p.trace && lane == 0) {
         uint64_t *t = p.trace + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * W + w) * 4u;
         t[0] = t_start;

@@ -108,6 +108,19 @@ int main(int argc, char **argv)
         if (!strcasecmp(a, "--printseq")) print_seq = 1;
         else if (!strcasecmp(a, "--printfasta")) print_fasta = 1;
         else if (!strcasecmp(a, "--printmatrices") || !strcasecmp(a, "--pretty") || !strcasecmp(a, "--colour")) {
+        } else if (!strcasecmp(a, "--stdin")) {
+            /* reference src/alignment_cmdline.c:219-222: cmdline_set_files(cmd, "", NULL) -- a query path
+             * and NO database, which its cmdline_new then refuses with "No input specified" (:303-305) */
+            qpath = "";
+            dbpath = NULL;
+        } else if (!strcasecmp(a, "--packed")) { /* this tool's flag-only options: valid in last position too */
+            packed = 1;
+        } else if (!strcasecmp(a, "--align")) {
+            align = 1;
+        } else if (!strcasecmp(a, "--timing")) {
+            timing = 1;
+        } else if (!strcasecmp(a, "--allqueries")) {
+            allq = 1;
         } else if (i == argc - 1) {
             char msg[256];
             snprintf(msg, sizeof msg, "Unknown argument without parameter: %s", a);
@@ -137,14 +150,11 @@ int main(int argc, char **argv)
         } else if (!strcasecmp(a, "--savedb")) {
             if (i >= argc - 1) usage(argv[0], "--savedb takes a file name");
             savedb = argv[++i];
-        } else if (!strcasecmp(a, "--packed")) {
-            packed = 1;
-        } else if (!strcasecmp(a, "--align")) {
-            align = 1;
-        } else if (!strcasecmp(a, "--timing")) {
-            timing = 1;
-        } else if (!strcasecmp(a, "--allqueries")) {
-            allq = 1;
+        } else if (!strcasecmp(a, "--file")) {
+            /* reference src/alignment_cmdline.c:268-270: cmdline_set_files(cmd, argv[argi + 1], NULL) */
+            qpath = argv[i + 1];
+            dbpath = NULL;
+            i++;
         } else if (!strcasecmp(a, "--gpus")) {
             if (!parse_int(argv[i + 1], 1, 64, &gpus)) usage(argv[0], "Invalid --gpus argument");
             i++;
@@ -164,7 +174,7 @@ int main(int argc, char **argv)
             usage(argv[0], msg);
         }
     }
-    if (!qpath || !dbpath) usage(argv[0], "Both query and database files must be provided");
+    if (!qpath || !dbpath) usage(argv[0], "No input specified"); /* reference src/alignment_cmdline.c:303-305 */
     if (!have_matrix) usage(argv[0], "--substitution_matrix is required (the fill scores from the matrix only)");
     if (packed && (print_seq || print_fasta)) usage(argv[0], "--printseq/--printfasta need the FASTA database, not --packed");
     if ((packed || savedb || allq) && gpus > 0) usage(argv[0], "--packed/--savedb/--allqueries work with one GPU (--gpu)");

@@ -28,7 +28,9 @@ def main(budget=300.0, seed=1):
         if sum(lens) * lq > 6e9:
             continue
         sc = swg.load_scoring(str(rng.choice(mats)))
-        go, ge = [(-2, -1), (-10, -1), (0, -1), (-3, 0), (-11, -2)][int(rng.integers(0, 5))]
+        # (the last three: positive gap INCREMENTS -- gap_open + gap_extend > 0 or gap_extend > 0 -- which only the
+        # exact int32 form can express; the reference's CLI accepts them)
+        go, ge = [(-2, -1), (-10, -1), (0, -1), (-3, 0), (-11, -2), (5, -1), (0, 1), (1, -3)][int(rng.integers(0, 8))]
         q = swg.synth_query(int(rng.integers(1, 1 << 30)), lq)
         seqs = [swg.synth_query(int(rng.integers(1, 1 << 30)), L) for L in lens]
         if rng.random() < 0.12:   # scores beyond int16 and beyond 65535: tryptophan-rich query, copies of its prefixes

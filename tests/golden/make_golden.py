@@ -104,8 +104,33 @@ def emit(name, sub, go, ge, q, flat, offsets, lanes, ref_valid=True):
         name, len(offsets) - 1, len(q), len(flat), int(ora.max()), bool((ref == ora).all())))
 
 
+def equal_length_batches(rng, q, lengths):
+    """Batches whose 16 lanes all have the batch's length: nothing is padded, so the reference (which computes
+    padded rows as real rows) and the per-pair oracle agree even when gap scores are positive and a
+    gap through padding rows would keep gaining."""
+    seqs = [similar(rng, q, L) for L in lengths for _ in range(16)]
+    flat = np.concatenate(seqs)
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(s) for s in seqs])
+    return flat, offsets, np.full(len(lengths), 16, dtype=np.int32)
+
+
+def positive_gap_cases():
+    """Round 2: gap scores whose INCREMENT is positive (gap_open + gap_extend > 0, or gap_extend > 0): the
+    reference's CLI accepts them (src/alignment_cmdline.c:255-267), the packed int16 form cannot express them,
+    so they pin the exact int32 kernel and the traceback."""
+    rng = np.random.default_rng(20261004)
+    b62 = load_matrix("BLOSUM62")
+    q = rand_seq(rng, 150)
+    emit("blosum62_gap_pos5_m1", b62, 5, -1, q, *equal_length_batches(rng, q, [120, 90, 64, 33, 7, 1]))
+    emit("blosum62_gap_0_pos1", b62, 0, 1, q, *equal_length_batches(rng, q, [110, 80, 48, 16, 3]))
+
+
 def main():
     assert orc.have_ref(), "build oracle/_ref first (make -C oracle)"
+    if "--positive-gaps" in sys.argv:          # only the fixtures added in round 2 (the others stay byte for byte)
+        positive_gap_cases()
+        return
     rng = np.random.default_rng(20250523)
     pam, b62, b45 = load_matrix("PAM250"), load_matrix("BLOSUM62"), load_matrix("BLOSUM45")
 
@@ -149,6 +174,7 @@ def main():
     offsets = np.zeros(17, dtype=np.uint64)
     offsets[1:] = np.cumsum(lens)
     emit("pam250_overflow_w", pam, -2, -1, q, flat, offsets, np.array([16], dtype=np.int32), ref_valid=False)
+    positive_gap_cases()
 
 
 if __name__ == "__main__":

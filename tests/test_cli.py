@@ -54,6 +54,20 @@ def test_cli_argument_handling(swg, tmp_path):
     assert r.returncode != 0 and "--gapopen" in r.stderr
     r = _run("--substitution_matrix", B62, "--align", "--files", str(q), str(q))
     assert r.returncode != 0 and "--topk" in r.stderr
+    # the reference's --stdin and --file <f> (src/alignment_cmdline.c:219-222, 268-270) name a query and no
+    # database: accepted by the parser, then refused like the reference's cmdline_new does (:303-305)
+    for extra in (["--stdin"], ["--file", str(q)]):
+        r = _run("--substitution_matrix", B62, *extra)
+        assert r.returncode != 0 and "No input specified" in r.stderr and "Unknown argument" not in r.stderr, extra
+    # ... and a later --files still wins
+    r = _run("--substitution_matrix", B62, "--file", str(q), "--files", str(q), str(q))
+    assert "No input specified" not in r.stderr
+    # flag-only options are valid in the last position (the reference's own are: --printseq etc.)
+    for last in ("--timing", "--align", "--packed", "--allqueries", "--printseq", "--printfasta", "--stdin"):
+        r = _run("--substitution_matrix", B62, "--files", str(q), str(q), last)
+        assert "without parameter" not in r.stderr, last
+    r = _run("--substitution_matrix", B62, "--files", str(q), str(q), "--topk")
+    assert r.returncode != 0 and "Unknown argument without parameter: --topk" in r.stderr
 
 
 def test_cli_refuses_without_gpu(swg, tmp_path):

@@ -68,7 +68,8 @@ def test_golden_forced_int32(swg, ctx, name, engine):
 
 
 @pytest.mark.parametrize("name", ["pam250_lq128", "blosum62_lq367", "pam250_partial_lanes",
-                                  "blosum62_gap_0_1", "blosum62_gap_pos1_m3", "blosum62_query_bzx"])
+                                  "blosum62_gap_0_1", "blosum62_gap_pos1_m3", "blosum62_query_bzx",
+                                  "blosum62_gap_pos5_m1", "blosum62_gap_0_pos1"])
 def test_golden_through_reference_shaped_batches(swg, ctx, orc, name):
     """swg_fill_batches16 replays exactly what alignment_fill_matrices receives."""
     g = load_golden(name)
@@ -394,6 +395,8 @@ def test_full_size_config2_properties(swg, ctx, orc):
     db = swg.Database(flat, off).upload(ctx)
     base, hits, st = ctx.search(db, k=100)
     assert st["engine"] == 2 and st["path_bits"] == 16
+    # the long pairs are a class of their own, launched on a second stream: measured to have run BESIDE the bulk
+    assert st["long_pairs"] > 0 and st["classes_overlapped"] == 1
     # independent paths
     ctx.set_option("engine", 1)
     assert np.array_equal(ctx.search(db)[0], base)

@@ -23,7 +23,7 @@ def test_abi_exports_every_declared_symbol(swg):
     for n in names:
         assert hasattr(swg.lib, n), "libswg.so does not export " + n
     assert sorted(names) == sorted(swg.ABI_SYMBOLS)
-    assert swg.lib.swg_abi_version() == 1
+    assert swg.lib.swg_abi_version() == 2
 
 
 def test_no_cpu_fallback(swg):
@@ -358,3 +358,18 @@ def test_packed_image_is_deterministic(swg, tmp_path):
     assert a.read_bytes() == b.read_bytes()
     db = swg.Database(path=str(a))
     assert db.count == 1000 and db.residues == len(flat)
+
+
+def test_built_kernels_keep_unfused_lds_reads(swg):
+    """The build disables hipcc's load/store optimizer for device code so that the profile reads stay
+    ds_read_b64 (conflict-free 8-byte bank slots) instead of being fused into ds_read2_b64 (half the bytes per
+    LDS cycle).  If a compiler update dropped or renamed that switch nothing else would notice: the build
+    looks at the code object it produced (build.verify_isa) and records the library it checked."""
+    import swg_loader
+    b = swg_loader.build_module()
+    b.ensure_isa_checked(verbose=False)                    # a no-op when this library was checked at build time
+    stamp = open(b.ISA_STAMP).read().split("\n")
+    assert stamp[0] == b._lib_digest()
+    counts = eval(stamp[1], {"__builtins__": {}})
+    for fam in ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_diag32q_kernel"):
+        assert counts[fam][0] > 0 and counts[fam][1] == 0, fam

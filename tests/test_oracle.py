@@ -89,7 +89,7 @@ def test_oracle_alignment_paths_score_what_the_reference_scored(orc):
     """sw_oracle_pair_trace: the path's substitution and gap scores add up to the score the
     reference's own fill produced for the pair (the path itself has no reference output: the fork
     removed the traceback), its coordinates bound the path, and it ends on a residue pair."""
-    for name in ("pam250_lq128", "blosum62_gap_10_1", "blosum62_gap_0_1", "blosum62_gap_pos1_m3", "blosum62_query_bzx",
+    for name in ("pam250_lq128", "blosum62_gap_10_1", "blosum62_gap_0_1", "blosum62_gap_pos1_m3", "blosum62_gap_pos5_m1", "blosum62_gap_0_pos1", "blosum62_query_bzx",
                  "blosum62_tiny_db", "blosum62_lq1"):
         g = load_golden(name)
         go, ge = int(g["gaps"][0]), int(g["gaps"][1])
