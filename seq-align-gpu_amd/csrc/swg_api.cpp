@@ -448,10 +448,11 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
 }
 
 static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom, int k_real = 1,
-                               int k_padded = 1, int chunk_cols = 4)
+                               int k_padded = 1, int chunk_cols = 4, int swizzle_lanes = 0)
 {
     const size_t bytes = (size_t)ncols * 32 * elem_size;
-    const uint64_t tag = (ctx->epoch << 32) ^ geom;
+    // (query, scoring) epoch and geometry: the epoch is spread over all 64 bits so that no geometry field can alias it
+    const uint64_t tag = (ctx->epoch * 0x9E3779B97F4A7C15ull) ^ geom ^ ((uint64_t)swizzle_lanes << 56) ^ ((uint64_t)chunk_cols << 60);
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
     if (bytes > ctx->d_profile_cap[which]) {
         (void)hipFree(ctx->d_profile[which]);
@@ -461,7 +462,8 @@ static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem
         ctx->d_profile_cap[which] = bytes;
     }
     HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols,
-                                          elem_size, chunk_cols, k_real, k_padded, ctx->d_profile[which], ctx->stream));
+                                          elem_size, chunk_cols, k_real, k_padded, ctx->d_profile[which], ctx->stream,
+                                          swizzle_lanes));
     ctx->profile_tag[which] = tag;
     return SWG_OK;
 }
@@ -640,40 +642,34 @@ static int ensure_scratch(swg_ctx *ctx, size_t dwords)
 // ---------------------------------------------------------------------------
 // diagonal engine: make a work plan resident, launch it
 // ---------------------------------------------------------------------------
-// Which profile buffer a class reads: [0] the plain [col/4][32][4] layout, which every geometry with
-// whole chunks per lane (K % 4 == 0) slices the same way; a K that is not a multiple of 4 pads every
-// lane's slice to whole chunks, a layout of its own: [3] for the bulk, [2] for the long class.
-static int diag_profile_slot(const SwgDiagPlan &pl, int cls) { return pl.K % 4 == 0 ? 0 : cls == 0 ? 3 : 2; }
+// Which profile buffer a class reads: every class has its own ([3] the bulk, [2] the long class) -- a
+// lane's slice is its K columns padded to whole chunks, its rows swizzled by the lane's position in a
+// group of G: the layout depends on (K, G).  ([0] and [1] are the systolic engine's, in plain order.)
+static int diag_profile_slot(const SwgDiagPlan &, int cls) { return cls == 0 ? 3 : 2; }
 
 static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
 {
-    uint32_t ncols[4] = {0, 0, 0, 0};
-    int own_k[4] = {0, 0, 0, 0};
     if (ctx->opt_dynamic) {
         int rc = ensure_pair_tokens(ctx, db);
         if (rc != SWG_OK) return rc;
     }
     for (int c = 0; c < wk.n_classes; ++c) {
-        if (!diag_class_is_dynamic(ctx, db, wk.plan[c])) {
-            int rc = ensure_diag_layout(ctx, db, c, wk.plan[c], wk.pair_begin[c], wk.pair_end[c]);
+        const SwgDiagPlan &pl = wk.plan[c];
+        if (!diag_class_is_dynamic(ctx, db, pl)) {
+            int rc = ensure_diag_layout(ctx, db, c, pl, wk.pair_begin[c], wk.pair_end[c]);
             if (rc != SWG_OK) return rc;
-        } else if (wk.plan[c].npass > 1 && !db->ptok.d_edge[0]) {
+        } else if (pl.npass > 1 && !db->ptok.d_edge[0]) {
             const size_t bytes = std::max<size_t>(8, (size_t)db->ptok.total_blocks * 4 * sizeof(uint2));
             HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[0], bytes));
             HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[1], bytes));
         }
-        const int slot = diag_profile_slot(wk.plan[c], c);
-        ncols[slot] = std::max<uint32_t>(ncols[slot], (uint32_t)(wk.plan[c].npass * wk.plan[c].G *
-                                                                 swg_diag_padded_cols(wk.plan[c].K)));
-        if (slot != 0) own_k[slot] = wk.plan[c].K;
+        const int kp = swg_diag_padded_cols(pl.K);
+        const uint32_t ncols = (uint32_t)(pl.npass * pl.G * kp);
+        int rc = ensure_profile_cols(ctx, diag_profile_slot(pl, c), ncols, 2,
+                                     (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols, pl.K, kp, 4,
+                                     SWG_LDS_SWIZZLE ? pl.G : 0);
+        if (rc != SWG_OK) return rc;
     }
-    for (int slot = 0; slot < 4; ++slot)
-        if (slot != 1 && ncols[slot]) {
-            int rc = slot != 0 ? ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ((uint64_t)own_k[slot] << 24) ^ ncols[slot],
-                                                     own_k[slot], swg_diag_padded_cols(own_k[slot]))
-                               : ensure_profile_cols(ctx, slot, ncols[slot], 2, (1ull << 31) ^ ncols[slot]);
-            if (rc != SWG_OK) return rc;
-        }
     return SWG_OK;
 }
 
@@ -963,8 +959,8 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
     for (int c = 0; c < wk.n_classes; ++c) {
         const SwgDiagPlan &pl = wk.plan[c];
         const int kp = swg_q32_padded_cols(pl.K);
-        int rc = ensure_profile_cols(ctx, 4 + c, (uint32_t)(pl.G * kp), 4, (1ull << 33) ^ ((uint64_t)pl.K << 24) ^ (uint64_t)(pl.G * kp),
-                                     pl.K, kp, 2);
+        int rc = ensure_profile_cols(ctx, 4 + c, (uint32_t)(pl.G * kp), 4, (1ull << 54) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)(pl.G * kp),
+                                     pl.K, kp, 2, SWG_LDS_SWIZZLE ? pl.G : 0);
         if (rc != SWG_OK) return rc;
     }
     if (timing_events) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
@@ -1879,7 +1875,7 @@ extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *qu
             const SwgDiagPlan &pl = wk.plan[c];
             HIP_TRY(ctx, swg_launch_build_profiles_multi(ctx->d_sub, B.d_q, B.d_qoff, (uint32_t)Qb,
                                                          (uint32_t)(pl.G * swg_diag_padded_cols(pl.K)), pl.K,
-                                                         swg_diag_padded_cols(pl.K), B.d_prof[c], s));
+                                                         swg_diag_padded_cols(pl.K), B.d_prof[c], s, SWG_LDS_SWIZZLE ? pl.G : 0));
         }
         // workgroups per query: the chip's resident workgroups shared out over the batch
         int wgs[2] = {1, 1};

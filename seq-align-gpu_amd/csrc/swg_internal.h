@@ -140,16 +140,26 @@ hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int wo
 // profile of ncols layout columns goes to d_profiles + i * ncols * 32 * 2 (int16)
 hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off,
                                            uint32_t n_queries, uint32_t ncols, int k_real, int k_padded,
-                                           uint8_t *d_profiles, hipStream_t stream);
+                                           uint8_t *d_profiles, hipStream_t stream, int swizzle_lanes = 0);
+
+// LDS bank swizzle of the lane-group kernels' profile (1 = on): lane g of a group keeps the row of residue r
+// of each of its chunks at position r ^ (g & 31) instead of r, and forms its read address with an XOR instead
+// of an add (same instruction count).  Lanes of one LDS access that hold the SAME residue -- the common
+// case, proteins being what they are -- then read different bank pairs instead of the same one.
+#ifndef SWG_LDS_SWIZZLE
+#define SWG_LDS_SWIZZLE 1
+#endif
 
 // profile[(col/4)*32*4 + code*4 + col%4] = sub[query[col]][code] (code 0 and
 // col >= lq: pad value).  elem_size 2 -> int16 pad -32768, 4 -> int32 pad -2^29.
 // chunk_cols: columns per chunk, [col/chunk][32][chunk] (4 everywhere except diagonal K % 4 == 2)
 // k_real / k_padded: a lane's slice of the diagonal engine is k_padded layout columns holding k_real
 // query columns (equal everywhere except for an odd K); ncols counts layout columns
+// swizzle_lanes: 0 = rows in residue order (systolic engine, bin-based int32 kernel); G = the lane-group
+// width of the kernel that will read it: a lane's rows are stored at residue ^ (lane-in-group & 31)
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
                                     uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols, int k_real,
-                                    int k_padded, uint8_t *d_profile, hipStream_t stream);
+                                    int k_padded, uint8_t *d_profile, hipStream_t stream, int swizzle_lanes = 0);
 int swg_diag_padded_cols(int K); // layout columns of a lane's slice
 
 // Per-database layouts from the uploaded residue dwords (d_code_off in dwords): the pair-major

@@ -80,6 +80,23 @@ DEVINL uint32_t pk_max_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a),
                                                                   __builtin_bit_cast(s16x2, b)));
 }
+// LDS access by 32-bit LDS address: the lane-group kernels form their profile addresses with one SDWA
+// instruction from a per-lane base that already holds the array's LDS address (no add of the array
+// symbol per read).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+DEVINL uint2 lds_read_u2(uint32_t addr)
+{
+    const u32x2 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2 *>((uintptr_t)addr);
+    return make_uint2(v.x, v.y);
+}
+DEVINL int2 lds_read_i2(uint32_t addr)
+{
+    const i32x2 v = *reinterpret_cast<__attribute__((address_space(3))) const i32x2 *>((uintptr_t)addr);
+    return make_int2(v.x, v.y);
+}
+// 32-bit LDS address of a __shared__ array
+#define SWG_LDS_ADDRESS(arr) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(arr))
 DEVINL int imax(int a, int b) { return a > b ? a : b; }
 DEVINL int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
 
@@ -473,25 +490,25 @@ template <int K, bool WIDE = false> struct CellsDiag {
         mdl = (mdl & ~fm) | (ZERO & fm);
     }
 
-    // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows).  ax / ay: LDS byte
+    // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows).  ax / ay: 32-bit LDS
     // address of the row's residue in this lane's first chunk, for sequence X / Y.  FENCED: software
     // pipeline with a depth of one chunk -- chunk c+1's profile reads are issued before chunk c's
     // arithmetic and nothing moves across the chunk boundary, so at most two chunks' words (8
     // registers) are in flight.  Left alone the scheduler hoists eight reads and K=24 spills.
     template <bool FENCED = false>
-    DEVINL uint2 row(const uint8_t *prof, uint32_t ax, uint32_t ay, uint32_t em, uint32_t eb, uint32_t go, uint32_t ge)
+    DEVINL uint2 row(uint32_t ax, uint32_t ay, uint32_t em, uint32_t eb, uint32_t go, uint32_t ge)
     {
         constexpr int NCH = KP / CH;
         uint32_t md = mdl;
         uint32_t gl = sub(em, go);
         uint32_t bl = eb;
-        uint2 nx = *reinterpret_cast<const uint2 *>(prof + ax), ny = *reinterpret_cast<const uint2 *>(prof + ay);
+        uint2 nx = lds_read_u2(ax), ny = lds_read_u2(ay);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const uint2 wx = nx, wy = ny;
             if (c + 1 < NCH) {
-                nx = *reinterpret_cast<const uint2 *>(prof + ax + (c + 1) * CHUNK);
-                ny = *reinterpret_cast<const uint2 *>(prof + ay + (c + 1) * CHUNK);
+                nx = lds_read_u2(ax + (c + 1) * CHUNK);
+                ny = lds_read_u2(ay + (c + 1) * CHUNK);
             }
             uint32_t s[CH];
             s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
@@ -544,10 +561,30 @@ DEVINL int opaque_uniform(int v)
     return v;
 }
 
+// LDS address of a residue's row in a lane's first profile chunk.  base: the lane's slice (multiple of 256)
+// with, when the profile is swizzled, (g & 31) << 3 in its low byte; off: the token's residue byte.
+// BYTE: which byte of the token (0: sequence X, 1: sequence Y).  One SDWA instruction either way; the XOR is
+// written out because the compiler's SDWA peephole only finds the add (it makes v_and + v_bfe + 2 v_xad of the XOR).
+template <int BYTE> DEVINL uint32_t prof_addr(uint32_t base, uint32_t tok)
+{
+#if SWG_LDS_SWIZZLE
+    uint32_t a;
+    if (BYTE == 0)
+        asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(base), "v"(tok));
+    else
+        asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(base), "v"(tok));
+    return a;
+#else
+    return base + ((tok >> (8 * BYTE)) & 0xFFu);
+#endif
+}
+// slice_base: LDS address of the lane's slice, a multiple of 256 (the arrays are declared aligned(256))
+DEVINL uint32_t prof_base(uint32_t slice_base, int g) { return SWG_LDS_SWIZZLE ? (slice_base | (((uint32_t)g & 31u) << 3)) : slice_base; }
+
 template <int K, int MAXW, bool MULTIPASS, bool WIDE = false>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile of this pass
+    extern __shared__ __attribute__((aligned(256))) uint8_t smem[]; // query profile of this pass
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int W = (int)(blockDim.x >> 6);
@@ -569,7 +606,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
     const uint32_t rows = nblk * 4u;
     const uint4 *tp = p.tok + boff;
     uint2 *sp = p.scratch + boff * 4u;
-    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / 4) * CellsDiag<K>::CHUNK;
+    const uint32_t base = prof_base(SWG_LDS_ADDRESS(smem) + (uint32_t)g * (CellsDiag<K>::KP / 4) * CellsDiag<K>::CHUNK, g);
     const uint32_t slice = (uint32_t)G * CellsDiag<K>::KP * 64u;
     const int npass = MULTIPASS ? (int)p.npass : 1;
 
@@ -644,7 +681,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
                         ge_t |= fm;
                     }
                 }
-                const uint2 e = cells.template row<(K > 16)>(smem, base + (tok & 0xFFu), base + ((tok >> 8) & 0xFFu), em,
+                const uint2 e = cells.template row<(K > 16)>(prof_addr<0>(base, tok), prof_addr<1>(base, tok), em,
                                                               eb, go_t, ge_t);
                 c_out = pk_max_i16(cin, cells.best);
                 if (special && tail && (tok & SWG_TOK_LAST)) {
@@ -760,7 +797,7 @@ template <int K, int MAXW, bool EDGES = false, bool WIDE = false>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDynParams p)
 {
     static_assert(EDGES || !WIDE, "the wide form is instantiated with edges only");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // query profile, then the group records
+    extern __shared__ __attribute__((aligned(256))) uint8_t smem[]; // query profile, then the group records
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int W = (int)(blockDim.x >> 6);
@@ -769,7 +806,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     const int g = lane & (G - 1);
     const bool leader = g == 0, tail = g == G - 1;
     constexpr uint32_t Z = CellsDiag<K, WIDE>::ZERO; // score 0 in the cells' representation
-    const uint32_t base = (uint32_t)g * (CellsDiag<K>::KP / 4) * CellsDiag<K>::CHUNK;
+    const uint32_t base = prof_base(SWG_LDS_ADDRESS(smem) + (uint32_t)g * (CellsDiag<K>::KP / 4) * CellsDiag<K>::CHUNK, g);
     const uint32_t slice = (uint32_t)G * CellsDiag<K>::KP * 64u;
     // recomputed where it is needed (rarely) instead of living in a register
     auto record = [&]() -> uint32_t * {
@@ -964,7 +1001,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     ge_v |= fm;
                 }
             }
-            const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(smem, base + (tok & 0xFFu), base + ((tok >> 8) & 0xFFu),
+            const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(prof_addr<0>(base, tok), prof_addr<1>(base, tok),
                                                                            em, eb, go_v, ge_v);
             if (special) {
                 if (!WIDE) {
@@ -1049,17 +1086,17 @@ template <int K> struct CellsQ32 {
     }
 
     // em / eb: M and B of the column left of this lane's strip in this row; go / ge: gap magnitudes
-    template <bool FENCED = false> DEVINL int2 row(const uint8_t *prof, uint32_t ax, int em, int eb, int go, int ge)
+    template <bool FENCED = false> DEVINL int2 row(uint32_t ax, int em, int eb, int go, int ge)
     {
         constexpr int NCH = KP / 2;
         int md = mdl;
         int gl = em - go;
         int bl = eb;
-        int2 nx = *reinterpret_cast<const int2 *>(prof + ax);
+        int2 nx = lds_read_i2(ax);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int2 w = nx;
-            if (c + 1 < NCH) nx = *reinterpret_cast<const int2 *>(prof + ax + (c + 1) * CHUNK);
+            if (c + 1 < NCH) nx = lds_read_i2(ax + (c + 1) * CHUNK);
             const int s[2] = {w.x, w.y};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1088,14 +1125,14 @@ template <int K> struct CellsQ32 {
 template <int K, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32Params p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; // int32 query profile, then the group records
+    extern __shared__ __attribute__((aligned(256))) uint8_t smem[]; // int32 query profile, then the group records
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int G = (int)p.G;
     const int gshift = G == 16 ? 4 : G == 32 ? 5 : 6;
     const int g = lane & (G - 1);
     const bool leader = g == 0, tail = g == G - 1;
-    const uint32_t base = (uint32_t)g * (CellsQ32<K>::KP / 2) * CellsQ32<K>::CHUNK;
+    const uint32_t base = prof_base(SWG_LDS_ADDRESS(smem) + (uint32_t)g * (CellsQ32<K>::KP / 2) * CellsQ32<K>::CHUNK, g);
     const uint32_t slice = (uint32_t)G * CellsQ32<K>::KP * 128u;
     auto record = [&]() -> uint32_t * {
         const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -1235,7 +1272,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                 go_v = (int)(((uint32_t)go_v & ~fm) | (SWG_Q32_RESET_GAP & fm));
                 ge_v = (int)(((uint32_t)ge_v & ~fm) | (SWG_Q32_RESET_GAP & fm));
             }
-            const int2 e = cells.template row<(K > 12)>(smem, base + (tok & 0xFFu), em, eb, go_v, ge_v);
+            const int2 e = cells.template row<(K > 12)>(prof_addr<0>(base, tok), em, eb, go_v, ge_v);
             if (special) {
                 go_v = (int)p.go;
                 ge_v = (int)p.ge;
@@ -1264,7 +1301,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
 // ---------------------------------------------------------------------------
 __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
                                          uint32_t ncols, int elem_size, uint32_t ch, uint32_t k_real,
-                                         uint32_t k_padded, uint8_t *out)
+                                         uint32_t k_padded, uint32_t swizzle_lanes, uint8_t *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
     if (t >= ncols * 32u) return;
@@ -1273,7 +1310,9 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
     const uint32_t j = col % k_padded, qcol = (col / k_padded) * k_real + j;
     const bool pad = (j >= k_real) || (qcol >= lq) || (code == 0u);
     const int v = pad ? 0 : (int)sub[(int)query[qcol] * 32 + (int)code];
-    const size_t e = (size_t)(col / ch) * (32u * ch) + code * ch + (col % ch); // [col/ch][32][ch]
+    // row of this residue inside its chunk: the residue itself, or swizzled by the reading lane (SWG_LDS_SWIZZLE)
+    const uint32_t row = swizzle_lanes ? code ^ (((col / k_padded) % swizzle_lanes) & 31u) : code;
+    const size_t e = (size_t)(col / ch) * (32u * ch) + row * ch + (col % ch); // [col/ch][32][ch]
     if (elem_size == 2)
         reinterpret_cast<int16_t *>(out)[e] = pad ? (int16_t)-32768 : (int16_t)v;
     else
@@ -1282,7 +1321,8 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
 
 // The same for several queries at once (swg_search_multi): grid.y = query; int16, 4-column chunks.
 __global__ void swg_build_profiles_multi_kernel(const int8_t *sub, const int8_t *queries, const uint32_t *q_off,
-                                                uint32_t ncols, uint32_t k_real, uint32_t k_padded, uint8_t *out)
+                                                uint32_t ncols, uint32_t k_real, uint32_t k_padded, uint32_t swizzle_lanes,
+                                                uint8_t *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
     if (t >= ncols * 32u) return;
@@ -1293,17 +1333,19 @@ __global__ void swg_build_profiles_multi_kernel(const int8_t *sub, const int8_t 
     const uint32_t j = col % k_padded, qcol = (col / k_padded) * k_real + j;
     const bool pad = (j >= k_real) || (qcol >= lq) || (code == 0u);
     const int v = pad ? 0 : (int)sub[(int)query[qcol] * 32 + (int)code];
-    const size_t e = (size_t)(col / 4u) * 128u + code * 4u + (col % 4u); // [col/4][32][4]
+    const uint32_t row = swizzle_lanes ? code ^ (((col / k_padded) % swizzle_lanes) & 31u) : code;
+    const size_t e = (size_t)(col / 4u) * 128u + row * 4u + (col % 4u); // [col/4][32][4]
     reinterpret_cast<int16_t *>(out + (size_t)qi * ncols * 64u)[e] = pad ? (int16_t)-32768 : (int16_t)v;
 }
 
 hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off,
                                            uint32_t n_queries, uint32_t ncols, int k_real, int k_padded,
-                                           uint8_t *d_profiles, hipStream_t stream)
+                                           uint8_t *d_profiles, hipStream_t stream, int swizzle_lanes)
 {
     if (n_queries == 0 || ncols == 0) return hipSuccess;
     hipLaunchKernelGGL(swg_build_profiles_multi_kernel, dim3((ncols * 32u + 255u) / 256u, n_queries), dim3(256), 0, stream,
-                       d_sub, d_queries, d_q_off, ncols, (uint32_t)k_real, (uint32_t)k_padded, d_profiles);
+                       d_sub, d_queries, d_q_off, ncols, (uint32_t)k_real, (uint32_t)k_padded, (uint32_t)swizzle_lanes,
+                       d_profiles);
     return hipGetLastError();
 }
 
@@ -1870,11 +1912,12 @@ hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups, const S
 
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, uint32_t lq,
                                     uint32_t ncols, int elem_size, int chunk_cols, int k_real, int k_padded,
-                                    uint8_t *d_profile, hipStream_t stream)
+                                    uint8_t *d_profile, hipStream_t stream, int swizzle_lanes)
 {
     const uint32_t n = ncols * 32u;
     hipLaunchKernelGGL(swg_build_profile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_sub,
-                       d_query, lq, ncols, elem_size, (uint32_t)chunk_cols, (uint32_t)k_real, (uint32_t)k_padded, d_profile);
+                       d_query, lq, ncols, elem_size, (uint32_t)chunk_cols, (uint32_t)k_real, (uint32_t)k_padded,
+                       (uint32_t)swizzle_lanes, d_profile);
     return hipGetLastError();
 }
 

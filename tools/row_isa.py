@@ -54,7 +54,7 @@ def kind(op):
 
 # rows are unrolled four times; a row's profile addresses are formed by two SDWA adds (residue bytes 0
 # and 1 of the token): a row is taken from one BYTE_0 add to the next
-starts = [i for i, l in enumerate(body) if "v_add_u32_sdwa" in l and "BYTE_0" in l]
+starts = [i for i, l in enumerate(body) if ("v_add_u32_sdwa" in l or "v_xor_b32_sdwa" in l) and "BYTE_0" in l]
 a, b = starts[1], starts[2]
 mix = collections.Counter()
 others = []
