@@ -19,8 +19,8 @@ text = ""
 for co in sorted(glob.glob(lib + ".*gfx950")):
     text += subprocess.run([OBJDUMP, "-d", co], stdout=subprocess.PIPE, text=True).stdout
 lines = text.split("\n")
-name = "_Z19swg_diag_dyn_kernelILi%dELi16ELb0ELb0E" % K
-start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <%s" % name, l))
+name = "_Z19swg_diag_dyn_kernelILi%dELi" % K     # <K, waves the instantiation was compiled for, no edges, not wide>
+start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <%s\d+ELb0ELb0E" % name, l))
 end = start + 1
 while end < len(lines) and not re.match(r"^[0-9a-f]+ <_Z", lines[end]):
     end += 1
