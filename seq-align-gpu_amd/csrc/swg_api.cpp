@@ -537,7 +537,9 @@ static int ensure_pair_tokens(swg_ctx *ctx, swg_db *db)
     }
     T.total_blocks = T.pair_blocks_prefix.back();
     const uint32_t n_pairs = (uint32_t)(T.pair_blocks_prefix.size() - 1);
-    HIP_TRY(ctx, hipMalloc(&T.d_tok, std::max<size_t>(16, (size_t)T.total_blocks * 16)));
+    // (one more block, all zeros, behind the last pair: what lanes that feed no pair read)
+    HIP_TRY(ctx, hipMalloc(&T.d_tok, ((size_t)T.total_blocks + 1) * 16));
+    HIP_TRY(ctx, hipMemsetAsync(T.d_tok + T.total_blocks, 0, 16, ctx->stream));
     HIP_TRY(ctx, hipMalloc(&T.d_pair_off, T.pair_blocks_prefix.size() * 4));
     // (the host vector lives as long as the database: no wait needed for the copy)
     HIP_TRY(ctx, hipMemcpyAsync(T.d_pair_off, T.pair_blocks_prefix.data(), T.pair_blocks_prefix.size() * 4,
@@ -704,6 +706,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             SwgDiagDynParams q;
             memset(&q, 0, sizeof q);
             q.tok = T.d_tok;
+            q.zero_block = (uint32_t)T.total_blocks;
             q.pair_off = T.d_pair_off;
             q.q_begin = (uint32_t)wk.pair_begin[c];
             q.q_end = (uint32_t)wk.pair_end[c];
@@ -973,6 +976,7 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
         SwgDiagQ32Params q;
         memset(&q, 0, sizeof q);
         q.tok = T.d_tok;
+        q.zero_block = (uint32_t)T.total_blocks;
         q.pair_off = T.d_pair_off;
         uint64_t items;
         if (d_list) {
@@ -1902,6 +1906,7 @@ extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *qu
             SwgDiagDynParams q;
             memset(&q, 0, sizeof q);
             q.tok = T.d_tok;
+            q.zero_block = (uint32_t)T.total_blocks;
             q.pair_off = T.d_pair_off;
             q.q_begin = (uint32_t)wk.pair_begin[c];
             q.q_end = (uint32_t)wk.pair_end[c];

@@ -390,7 +390,7 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
     uint64_t total = 0;
     for (uint64_t p = 0; p < n_pairs; ++p) {
         total += (2ull + db->lens[2 * p] + 3) / 4;
-        if (total >= (1ull << 32)) return -1; // block offsets are 32-bit on the device
+        if (total + 1 >= (1ull << 32)) return -1; // block offsets are 32-bit on the device (and one block of zeros follows the last pair)
         (*pair_off)[p + 1] = (uint32_t)total;
     }
     if (!tok) return 0; // offsets only: the tokens themselves are built on the device

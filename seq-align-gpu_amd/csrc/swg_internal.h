@@ -57,6 +57,7 @@ struct SwgDiagParams {
 #define SWG_DYN_SIMD_SLOTS 8192u // wavefront-rank counters, one per physical SIMD (xcc, se, sh, cu, simd)
 struct SwgDiagDynParams {
     const uint4 *tok;         // pair-major token blocks (4 rows, one 32-bit token each), longest pair first
+    uint32_t zero_block;      // index of a block of zeros in tok (padding rows for lanes that feed no pair)
     const uint32_t *pair_off; // [n_pairs+1] block offset of each pair's tokens
     uint32_t q_begin, q_end;  // this launch serves pairs [q_begin, q_end) ...
     uint32_t *queue;          // ... handed out by these SWG_DYN_SHARDS counters (zero before the launch)
@@ -88,6 +89,7 @@ struct SwgDiagDynParams {
 // the ranks [q_begin, q_end) or the entries of a device-side list.
 struct SwgDiagQ32Params {
     const uint4 *tok;           // pair-major token blocks
+    uint32_t zero_block;        // index of a block of zeros in tok
     const uint32_t *pair_off;   // [n_pairs+1]
     uint32_t q_begin, q_end;    // ranks to score (list == NULL)
     const uint32_t *list;       // or: ranks to score ...

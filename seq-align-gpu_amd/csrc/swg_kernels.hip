@@ -828,14 +828,25 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     }
     __syncthreads();
 
-    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
     CellsDiag<K, WIDE> cells;
     cells.reset();
     uint32_t tok = 0u, m_out = Z, b_out = Z;
     uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
     uint32_t nlast = 0u;               // last rows this lane has seen = position of its pair in the group's rings
-    uint4 cur = none, nxt = none;
-    uint32_t bi = SWG_DYN_NONE;  // leader lane: next token block of the pair it feeds (none: idle)
+    // Tokens, single pass: T0..T3 are the rows of the block being worked on.  Each is re-loaded with the
+    // same row of the NEXT block right after its use (one block of time for the load to land), from the
+    // per-lane pointer tp: the leader's runs through its pair's blocks, everybody else's -- and an idle
+    // leader's -- stays on a block of zeros (padding rows).  No register copies between blocks, nothing
+    // to clear: nine VALU instructions fewer per block than loading whole blocks into cur / nxt, which
+    // the EDGES form keeps (it needs the block index anyway, and at K=32 it has no register to spare:
+    // the pointer form spilled inside the loop and ran 1 % slower there).
+    uint32_t T0 = 0u, T1 = 0u, T2 = 0u, T3 = 0u;
+    const uint32_t *const zero_blk = reinterpret_cast<const uint32_t *>(p.tok + p.zero_block);
+    const uint32_t *tp = zero_blk;
+    uint32_t tstep = 0u;         // dwords tp advances per block: 4 while the leader feeds a pair
+    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+    uint4 cur = none, nxt = none; // EDGES: the block being worked on, the next one
+    uint32_t bi = SWG_DYN_NONE;   // EDGES: leader lane: next token block of the pair it feeds (none: idle)
     // EDGES: block index of cur / nxt (leader), row index travelling with the token, left edges of
     // the current / next block (lanes 0..3 of a group, one row each)
     uint32_t bcur = SWG_DYN_NONE, bnxt = SWG_DYN_NONE, ridx = SWG_DYN_NONE;
@@ -908,8 +919,14 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 }
                 fl = (second ? SWG_DYN_SECOND : 0u) | (tried << 8);
                 if (nq != SWG_DYN_NONE) {
-                    bi = p.pair_off[nq];
-                    const uint32_t len = p.pair_off[nq + 1u] - bi;
+                    const uint32_t first = p.pair_off[nq];
+                    const uint32_t len = p.pair_off[nq + 1u] - first;
+                    if (EDGES) {
+                        bi = first;
+                    } else {
+                        tp = reinterpret_cast<const uint32_t *>(p.tok + first);
+                        tstep = 4u;
+                    }
                     end_at = blocks + len;
                     const uint32_t pushed = st[2];
                     st[SWG_DYN_RING + (pushed & (SWG_DYN_RING - 1u))] = nq;
@@ -917,6 +934,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     if (len >= (second ? p.prio_blocks2 : p.prio_blocks)) fl |= SWG_DYN_HOT;
                 } else {
                     end_at = SWG_DYN_NONE;
+                    tp = zero_blk;
+                    tstep = 0u;
                     bi = SWG_DYN_NONE;
                 }
                 st[0] = end_at;
@@ -935,16 +954,16 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             if (drain >= (uint32_t)G + 12u) break;
             drain += 4u;
         }
-        cur = nxt;
-        nxt = none;
         if (EDGES) {
+            cur = nxt;
+            nxt = none;
             bcur = bnxt;
             bnxt = bi;
             ec = en;
-        }
-        if (bi != SWG_DYN_NONE) {
-            nxt = p.tok[bi];
-            ++bi;
+            if (bi != SWG_DYN_NONE) {
+                nxt = p.tok[bi];
+                ++bi;
+            }
         }
         if (EDGES) {
             // lanes 0..3 of a group fetch the next block's left edges, one row each
@@ -954,7 +973,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t fresh = block_row(cur, r);
+            const uint32_t fresh = EDGES ? block_row(cur, r) : r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
             uint32_t lm = Z, lb = Z, fresh_ridx = SWG_DYN_NONE;
             if (EDGES) {
                 lm = quad_bcast(ec.x, r);
@@ -984,6 +1003,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     eb = u2;
                     if (EDGES) ridx = u4;
                 }
+            }
+            // this row of the next block (the register is free: its value went into the DPP move above)
+            if (!EDGES) {
+                if (r == 0) T0 = tp[0];
+                else if (r == 1) T1 = tp[1];
+                else if (r == 2) T2 = tp[2];
+                else T3 = tp[3];
             }
             // Rows with a flag are rare: ONE wave-uniform test (any token above 0xFFFF) keeps their
             // bookkeeping out of the common step; the recurrence itself is issued once, with per-lane
@@ -1040,6 +1066,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 if (tail && ridx != SWG_DYN_NONE && p.edge_out) p.edge_out[ridx] = e;
             }
         }
+        if (!EDGES) tp += tstep;
         ++blocks;
         if (!hot && (blocks & (SWG_DYN_TURN_EVERY - 1u)) == 0u) take_turn();
     }
@@ -1148,7 +1175,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     __syncthreads();
     const uint32_t n_items = p.list_count ? *p.list_count : p.q_end - p.q_begin;
 
-    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
     CellsQ32<K> cells;
     cells.reset();
     uint32_t tok = 0u;
@@ -1160,8 +1186,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     // were loaded under (pick_nxt, pick_cur), or the last rows of a sequence would be read with its
     // successor's.
     uint32_t pick = 0x0C020C00u, pick_nxt = 0x0C020C00u, pick_cur = 0x0C020C00u;
-    uint4 cur = none, nxt = none;
-    uint32_t bi = SWG_DYN_NONE;
+    // tokens as in swg_diag_dyn_kernel: the rows of the current block, each re-loaded for the next block right after its use
+    uint32_t T0 = 0u, T1 = 0u, T2 = 0u, T3 = 0u;
+    const uint32_t *const zero_blk = reinterpret_cast<const uint32_t *>(p.tok + p.zero_block);
+    const uint32_t *tp = zero_blk;
+    uint32_t tstep = 0u;
     uint32_t blocks = 0u, next_event = 0u, drain = 0u;
     bool hot = false;
     uint32_t rank;
@@ -1206,8 +1235,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                 if (item != SWG_DYN_NONE) seq = p.list ? p.list[item] : p.q_begin + item;
                 if (seq != SWG_DYN_NONE && seq < p.seq_limit) {
                     const uint32_t pr = seq >> 1;
-                    bi = p.pair_off[pr];
-                    const uint32_t len = p.pair_off[pr + 1u] - bi;
+                    const uint32_t first = p.pair_off[pr];
+                    const uint32_t len = p.pair_off[pr + 1u] - first;
+                    tp = reinterpret_cast<const uint32_t *>(p.tok + first);
+                    tstep = 4u;
                     end_at = blocks + len;
                     pick = 0x0C020C00u | (seq & 1u);
                     const uint32_t pushed = st[2];
@@ -1216,7 +1247,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                     if (len >= p.prio_blocks) fl |= SWG_DYN_HOT;
                 } else {
                     end_at = SWG_DYN_NONE;
-                    bi = SWG_DYN_NONE;
+                    tp = zero_blk;
+                    tstep = 0u;
                 }
                 st[0] = end_at;
                 st[1] = fl;
@@ -1231,18 +1263,12 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
             if (drain >= (uint32_t)G + 12u) break;
             drain += 4u;
         }
-        cur = nxt;
-        pick_cur = pick_nxt;
-        nxt = none;
-        if (bi != SWG_DYN_NONE) {
-            nxt = p.tok[bi];
-            pick_nxt = pick;
-            ++bi;
-        }
+        pick_cur = pick_nxt; // the block worked on now was loaded during the previous iteration ...
+        pick_nxt = pick;     // ... and the one loaded during this iteration belongs to the leader's current sequence
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             // the leader's token of this row: the residue byte of ITS sequence of the pair, and the flags
-            const uint32_t raw = block_row(cur, r);
+            const uint32_t raw = r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
             const uint32_t fresh = __builtin_amdgcn_perm(raw, raw, pick_cur);
             int em, eb;
             const int Gs = opaque_uniform(G);
@@ -1264,6 +1290,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                     eb = (int)u2;
                 }
             }
+            if (r == 0) T0 = tp[0];
+            else if (r == 1) T1 = tp[1];
+            else if (r == 2) T2 = tp[2];
+            else T3 = tp[3];
             const bool special = __builtin_amdgcn_ballot_w64(tok > 0xFFFFu) != 0ull;
             if (special) {
                 uint32_t fm = 0u - ((tok >> 16) & 1u);
@@ -1291,6 +1321,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
             m_out = e.x;
             b_out = e.y;
         }
+        tp += tstep;
         ++blocks;
         if (!hot) take_turn();
     }
