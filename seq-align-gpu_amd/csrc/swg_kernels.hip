@@ -1632,6 +1632,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32_kernel(const SwgFillPara
 
 __global__ void swg_topk_hist_kernel(const int32_t *scores, const uint32_t *order, uint32_t n, uint32_t *hist)
 {
+    // These few wavefronts run BESIDE the next search's fill (their own stream): at the default priority the
+    // persistent fill wavefronts starve them for milliseconds; at the top one they are done in microseconds.
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t h[SWG_TOPK_BINS];
     for (int i = threadIdx.x; i < SWG_TOPK_BINS; i += blockDim.x) h[i] = 0u;
     __syncthreads();
@@ -1646,35 +1649,43 @@ __global__ void swg_topk_hist_kernel(const int32_t *scores, const uint32_t *orde
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-// one block of 1024 threads: out[0] = threshold score T, out[1] = status (0 ok, 1 fall back)
-__global__ void swg_topk_threshold_kernel(const uint32_t *hist, uint32_t k, uint32_t cap, uint32_t *out)
+// One block of 256 threads, 16 bins each: out[0] = threshold score T, out[1] = status (0 ok, 1 fall back).
+// It runs beside the NEXT search's fill on its own stream, and a fill at K=32 leaves every SIMD's register
+// file 8 registers per lane short of full: a kernel that needs more cannot be placed until a fill workgroup
+// retires (round 1's form, 20 registers, "took" 3.8-5 ms on config 3; the histogram and compaction kernels
+// beside it, 8 and 6 registers, 20 us).  Hence the one-at-a-time loops and the register cap.
+#define SWG_TOPK_THR_THREADS 256
+__global__ __launch_bounds__(SWG_TOPK_THR_THREADS) __attribute__((amdgpu_num_vgpr(8))) void
+swg_topk_threshold_kernel(const uint32_t *hist, uint32_t k, uint32_t cap, uint32_t *out)
 {
-    __shared__ uint32_t part[1024];
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int PER = SWG_TOPK_BINS / SWG_TOPK_THR_THREADS;
+    __shared__ uint32_t part[SWG_TOPK_THR_THREADS];
     const int t = threadIdx.x;
-    uint32_t b[4], sum = 0;
-    for (int j = 0; j < 4; ++j) {
-        b[j] = hist[4 * t + j];
-        sum += b[j];
-    }
+    uint32_t sum = 0;
+#pragma unroll 1
+    for (int j = 0; j < PER; ++j) sum += hist[PER * t + j];
     part[t] = sum;
     __syncthreads();
-    // suffix sums: part[t] = entries in bins >= 4t
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t add = (t + d < 1024) ? part[t + d] : 0u;
+    // suffix sums: part[t] = entries in bins >= PER * t
+#pragma unroll 1
+    for (int d = 1; d < SWG_TOPK_THR_THREADS; d <<= 1) {
+        const uint32_t add = (t + d < SWG_TOPK_THR_THREADS) ? part[t + d] : 0u;
         __syncthreads();
         part[t] += add;
         __syncthreads();
     }
     const uint32_t total = part[0];
     const uint32_t want = k < total ? k : total;
-    const uint32_t above = (t + 1 < 1024) ? part[t + 1] : 0u; // entries in bins >= 4(t+1)
+    const uint32_t above = (t + 1 < SWG_TOPK_THR_THREADS) ? part[t + 1] : 0u; // entries in bins >= PER * (t + 1)
     if (want > 0 && above < want && part[t] >= want) {
         uint32_t acc = above;
-        int T = 4 * t;
-        for (int j = 3; j >= 0; --j) {
-            acc += b[j];
+        int T = PER * t;
+#pragma unroll 1
+        for (int j = PER - 1; j >= 0; --j) {
+            acc += hist[PER * t + j];
             if (acc >= want) {
-                T = 4 * t + j;
+                T = PER * t + j;
                 break;
             }
         }
@@ -1690,6 +1701,9 @@ __global__ void swg_topk_threshold_kernel(const uint32_t *hist, uint32_t k, uint
 __global__ void swg_topk_compact_kernel(const int32_t *scores, const uint32_t *order, uint32_t n,
                                         const uint32_t *thr, uint64_t *cand, uint32_t cap, uint32_t *count)
 {
+    // These few wavefronts run BESIDE the next search's fill (their own stream): at the default priority the
+    // persistent fill wavefronts starve them for milliseconds; at the top one they are done in microseconds.
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || thr[1] != 0u) return;
     const uint32_t oi = order[i];
@@ -1710,7 +1724,7 @@ hipError_t swg_launch_topk(const int32_t *d_scores, const uint32_t *d_order, uin
     const int blocks = (int)((n_slots + 255) / 256 < 512 ? (n_slots + 255) / 256 : 512);
     hipLaunchKernelGGL(swg_topk_hist_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, d_scores, d_order,
                        n_slots, d_hist);
-    hipLaunchKernelGGL(swg_topk_threshold_kernel, dim3(1), dim3(1024), 0, stream, d_hist, k, cap, d_thr);
+    hipLaunchKernelGGL(swg_topk_threshold_kernel, dim3(1), dim3(SWG_TOPK_THR_THREADS), 0, stream, d_hist, k, cap, d_thr);
     hipLaunchKernelGGL(swg_topk_compact_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, d_scores,
                        d_order, n_slots, d_thr, d_cand, cap, d_count);
     return hipGetLastError();
