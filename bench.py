@@ -562,8 +562,27 @@ def line_from(block, env, scaling):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """The ONE line of the contract, on the process's real stdout."""
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
+    global _REAL_STDOUT
     args = parse_args()
+    # Libraries chat on stdout (RCCL prints a version banner at communicator creation): everything but the
+    # result line goes to stderr, at file-descriptor level, so that stdout carries exactly one JSON line.
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     env = Env(args)
     K, W = args.steps, args.warmup
     if env.use_dist:
@@ -572,12 +591,12 @@ def main():
         n_full = args.nseq or CONFIGS[cnum].get("n_full", CONFIGS[cnum]["n"])
         block = run_config(env, cnum, K, W, sharded=True, n_override=n_full)
         if env.rank == 0:
-            print(json.dumps(line_from(block, env, "strong")), flush=True)
+            emit(line_from(block, env, "strong"))
     elif args.config:
         block = run_config(env, args.config, K, W, host_inclusive_leg=True, cpu_leg=True)
         out = line_from(block, env, "strong")
         out["configs"] = {str(args.config): {k: v for k, v in block.items() if k not in ("cpu_baseline", "host_inclusive")}}
-        print(json.dumps(out), flush=True)
+        emit(out)
     else:
         # the headline first (exactly K timed steps after W warm-up steps), then the other shapes with
         # step counts scaled to their step time so the whole run stays within minutes
@@ -597,7 +616,7 @@ def main():
                 out["scaling_reference"] = run_config(env, SHARDED, 2, 1, sharded=True,
                                                       n_override=CONFIGS[SHARDED]["n_full"])
         out["configs"] = blocks
-        print(json.dumps(out), flush=True)
+        emit(out)
     env.close()
 
 
