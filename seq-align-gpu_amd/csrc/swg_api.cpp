@@ -295,6 +295,8 @@ void swg_db_release_device(swg_db *db)
     (void)hipFree(db->ptok.d_pair_off);
     (void)hipFree(db->ptok.d_edge[0]);
     (void)hipFree(db->ptok.d_edge[1]);
+    (void)hipFree(db->ptok.d_edge32[0]);
+    (void)hipFree(db->ptok.d_edge32[1]);
     db->ptok = SwgPairTokens();
     for (SwgDiagLayout &L : db->diag) {
         (void)hipFree(L.d_tok);
@@ -920,11 +922,23 @@ static bool q32_plan_fits(const SwgDiagWork &wk, size_t lq)
     return true;
 }
 
-// Geometry for a list of `n_items` flagged sequences: few of them get 64 lanes each (the shortest
-// chain per row), many the widest single-pass geometry that still fits LDS.
+// Geometry for a list of `n_items` flagged sequences (or, with a plan the int16 planner's choice does not
+// fit, the whole database): few items get 64 lanes each (the shortest chain per row), many the narrowest
+// lane group that covers the query in one pass.  A query no single pass holds (LDS: G*K int32 columns of
+// 128 bytes in 160 KB, about 1150) takes several passes of the widest geometry for the item count.
 static bool q32_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_items, SwgDiagWork *wk)
 {
-    const int order[3] = {n_items <= 8u * (uint32_t)ctx->n_cu ? 64 : 16, 32, n_items <= 8u * (uint32_t)ctx->n_cu ? 16 : 64};
+    const bool few = n_items <= 8u * (uint32_t)ctx->n_cu;
+    const int order[3] = {few ? 64 : 16, 32, few ? 16 : 64};
+    auto set = [&](int v, int K, int G, int npass) {
+        *wk = SwgDiagWork();
+        wk->n_classes = 1;
+        wk->plan[0].variant = v;
+        wk->plan[0].K = K;
+        wk->plan[0].G = G;
+        wk->plan[0].W = 4;
+        wk->plan[0].npass = npass;
+    };
     for (int gi = 0; gi < 3; ++gi) {
         const int G = order[gi];
         int best = -1, bestK = 1 << 30;
@@ -936,33 +950,62 @@ static bool q32_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_items, SwgDi
             }
         }
         if (best >= 0) {
-            *wk = SwgDiagWork();
-            wk->n_classes = 1;
-            wk->plan[0].variant = best;
-            wk->plan[0].K = bestK;
-            wk->plan[0].G = G;
-            wk->plan[0].W = 4;
-            wk->plan[0].npass = 1;
+            set(best, bestK, G, 1);
             return true;
         }
     }
-    return false;
+    // several passes: the most columns per pass that fit LDS (few items: 64 lanes; many: 32)
+    const int G = few ? 64 : 32;
+    int best = -1, bestK = 0;
+    for (int v = 0; v < swg_num_diag_variants(); ++v) {
+        const int K = swg_diag_variant_info(v).K;
+        if (K > bestK && swg_diag32q_lds_bytes(K, G, 4) <= 160 * 1024) {
+            best = v;
+            bestK = K;
+        }
+    }
+    if (best < 0) return false;
+    const size_t cols = (size_t)G * bestK;
+    const size_t npass = (lq + cols - 1) / cols;
+    if (npass > 64) return false;
+    // the fewest columns per lane that still need no more passes (less padding in the last one)
+    for (int v = 0; v < swg_num_diag_variants(); ++v) {
+        const int K = swg_diag_variant_info(v).K;
+        if (K < bestK && (size_t)G * K * npass >= lq) {
+            best = v;
+            bestK = K;
+        }
+    }
+    set(best, bestK, G, (int)npass);
+    return true;
 }
 
 // Launches the int32 work-queue fill: every sequence of the plan's classes (list == NULL), or the
-// device-side list of ranks with one class.  Events as launch_diag.
+// device-side list of ranks with one class.  A plan of several passes (one class) is one launch per
+// pass, the rows' edges going from launch to launch through memory.  Events as launch_diag.
 static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int go, int ge, const uint32_t *d_list,
                       const uint32_t *d_list_count, uint32_t list_items, uint32_t *queue_words, bool *two_ends,
                       bool timing_events = true)
 {
     hipStream_t s = ctx->stream;
-    const SwgPairTokens &T = db->ptok;
+    SwgPairTokens &T = const_cast<swg_db *>(db)->ptok;
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     *two_ends = false;
+    const int npass = wk.plan[0].npass;
+    if (npass > 1) {
+        if (wk.n_classes != 1 || T.total_blocks >= (1ull << 28))
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "int32 multi-pass fill: plan not supported");
+        if (!T.d_edge32[0]) {
+            const size_t bytes = std::max<size_t>(8, (size_t)T.total_blocks * 4 * 2 * sizeof(int2));
+            HIP_TRY(ctx, hipMalloc(&T.d_edge32[0], bytes));
+            HIP_TRY(ctx, hipMalloc(&T.d_edge32[1], bytes));
+        }
+    }
     for (int c = 0; c < wk.n_classes; ++c) {
         const SwgDiagPlan &pl = wk.plan[c];
         const int kp = swg_q32_padded_cols(pl.K);
-        int rc = ensure_profile_cols(ctx, 4 + c, (uint32_t)(pl.G * kp), 4, (1ull << 54) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)(pl.G * kp),
+        const uint32_t ncols = (uint32_t)(pl.npass * pl.G * kp);
+        int rc = ensure_profile_cols(ctx, 4 + c, ncols, 4, (1ull << 54) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols,
                                      pl.K, kp, 2, SWG_LDS_SWIZZLE ? pl.G : 0);
         if (rc != SWG_OK) return rc;
     }
@@ -989,7 +1032,6 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
             items = q.q_end - q.q_begin;
         }
         q.queue = queue_words + (size_t)c * SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE;
-        q.profile = ctx->d_profile[4 + c];
         q.scores = db->d_scores;
         q.seq_limit = (uint32_t)n_slots;
         q.G = (uint32_t)pl.G;
@@ -1007,7 +1049,15 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
         } else {
             q.prio_blocks = c == 1 ? 0u : 0xFFFFFFFFu;
         }
-        HIP_TRY(ctx, swg_launch_diag32q(pl.variant, W, wgs, q, c == 1 ? ctx->stream2 : s));
+        const size_t slice = (size_t)pl.G * swg_q32_padded_cols(pl.K) * 128;
+        hipStream_t qs = c == 1 ? ctx->stream2 : s;
+        for (int pass = 0; pass < pl.npass; ++pass) {
+            if (pass > 0) HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, qs));
+            q.profile = ctx->d_profile[4 + c] + (size_t)pass * slice;
+            q.edge_in = pass > 0 ? T.d_edge32[(pass - 1) & 1] : nullptr;
+            q.edge_out = pass + 1 < pl.npass ? T.d_edge32[pass & 1] : nullptr;
+            HIP_TRY(ctx, swg_launch_diag32q(pl.variant, pl.npass > 1, W, wgs, q, qs));
+        }
     }
     if (wk.n_classes == 2) {
         HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[5], s));
@@ -1311,14 +1361,16 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // Non-positive gap scores and a query of one pass: the int32 work-queue kernel (8 instructions per
     // cell, any lane-group geometry, pairs off the queue) instead of the bin-based one (12 per cell,
     // 64 lanes x 16 columns whatever the query length).
-    bool q32_ok = fast_ok && use_diag32 && ctx->opt_dynamic != 0 && lq <= 64 * 32;
+    bool q32_ok = fast_ok && use_diag32 && ctx->opt_dynamic != 0;
     {
-        SwgDiagWork probe; // (LDS holds G * K int32 columns of at most 160 KB: about 1150)
+        SwgDiagWork probe; // (one pass up to about 1150 columns, else several)
         q32_ok = q32_ok && q32_list_plan(ctx, lq, 1, &probe);
     }
     if (q32_ok && (bits == 32 || may_saturate)) {
         if ((rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
-        q32_ok = db->ptok.ok;
+        SwgDiagWork probe;
+        q32_ok = db->ptok.ok && q32_list_plan(ctx, lq, 1, &probe) &&
+                 (probe.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28)); // (32-bit edge indices)
     }
     SwgDiagWork wk32;
     bool use_q32 = false;
@@ -1585,12 +1637,12 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         st.cols_per_wave = w32.plan[0].K;
         st.group_lanes = w32.plan[0].G;
         st.waves = q32_class_waves(ctx, w32, 0);
-        st.passes = 1;
+        st.passes = w32.plan[0].npass;
         const uint64_t items0 = 2 * (w32.pair_end[0] - w32.pair_begin[0]);
         st.workgroups = q32_class_workgroups(ctx, w32, 0, items0);
         st.streams = st.workgroups * st.waves * (64 / w32.plan[0].G);
         for (int c = 0; c < w32.n_classes; ++c)
-            st.cells_padded += 2ull * w32.plan[c].G * w32.plan[c].K *
+            st.cells_padded += 2ull * w32.plan[c].npass * w32.plan[c].G * w32.plan[c].K *
                                (uint64_t)(db->ptok.pair_blocks_prefix[w32.pair_end[c]] - db->ptok.pair_blocks_prefix[w32.pair_begin[c]]) * 4ull;
         if (w32.n_classes == 2) {
             st.long_pairs = (int32_t)(w32.pair_end[1] - w32.pair_begin[1]);

@@ -67,6 +67,7 @@ struct SwgPairTokens {
     uint4 *d_tok = nullptr;
     uint32_t *d_pair_off = nullptr;
     uint2 *d_edge[2] = {nullptr, nullptr};    // multi-pass: (M,B) per row between consecutive passes, ping-pong
+    int2 *d_edge32[2] = {nullptr, nullptr};   // the same for the int32 work-queue kernel: per row and per sequence of the pair
     std::vector<uint32_t> pair_blocks_prefix; // host copy of pair_off
 };
 

@@ -103,11 +103,15 @@ struct SwgDiagQ32Params {
     uint32_t prio_blocks;       // a wavefront feeding a sequence of >= this many blocks runs at raised priority
     uint32_t *simd_ranks;       // [SWG_DYN_SIMD_SLOTS] zero before the launch
     uint32_t turn_levels;
+    // one pass of several: (M, B) left edge per row from the previous pass (null: first), right edge per row
+    // for the next (null: last); index = 2 * (row's position in the pair-major token order) + (X or Y)
+    const int2 *edge_in;
+    int2 *edge_out;
 };
 int swg_q32_padded_cols(int K);
 size_t swg_diag32q_lds_bytes(int K, int G, int W);
 // variant: index into the diagonal variants (swg_diag_variant_info gives its K)
-hipError_t swg_launch_diag32q(int variant, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream);
+hipError_t swg_launch_diag32q(int variant, bool edges, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream);
 
 struct SwgKernelInfo {
     int bits;      // 16 or 32

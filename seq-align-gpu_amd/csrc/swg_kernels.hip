@@ -1149,7 +1149,11 @@ template <int K> struct CellsQ32 {
 
 #define SWG_Q32_RESET_GAP (1 << 29) // gap magnitude on reset rows: one such row zeroes A, G and B, two zero M
 
-template <int K, int MAXW>
+// EDGES: one pass of a query longer than G*K columns, as in swg_diag_dyn_kernel: the left edge (M, B) of every
+// row comes from the previous pass's launch and the right edge goes to the next one, indexed by
+// 2 * (the row's position in the pair-major token order) + (which sequence of the pair), so that both
+// sequences of a pair can be items of the same launch; scores are the maximum over the passes.
+template <int K, int MAXW, bool EDGES>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32Params p)
 {
     extern __shared__ __attribute__((aligned(256))) uint8_t smem[]; // int32 query profile, then the group records
@@ -1191,6 +1195,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     const uint32_t *const zero_blk = reinterpret_cast<const uint32_t *>(p.tok + p.zero_block);
     const uint32_t *tp = zero_blk;
     uint32_t tstep = 0u;
+    // EDGES: edge index of row 0 of the block tp points at / the block loaded during this iteration / the
+    // block being worked on (leader; none: idle), the index travelling with the token, left edges of the
+    // current / next block (lanes 0..3 of a group, one row each)
+    uint32_t rb_load = SWG_DYN_NONE, rb_nxt = SWG_DYN_NONE, rb_cur = SWG_DYN_NONE, ridx = SWG_DYN_NONE;
+    int2 ec = make_int2(0, 0), en = make_int2(0, 0);
     uint32_t blocks = 0u, next_event = 0u, drain = 0u;
     bool hot = false;
     uint32_t rank;
@@ -1239,6 +1248,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                     const uint32_t len = p.pair_off[pr + 1u] - first;
                     tp = reinterpret_cast<const uint32_t *>(p.tok + first);
                     tstep = 4u;
+                    if (EDGES) rb_load = first * 8u + (seq & 1u);
                     end_at = blocks + len;
                     pick = 0x0C020C00u | (seq & 1u);
                     const uint32_t pushed = st[2];
@@ -1249,6 +1259,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                     end_at = SWG_DYN_NONE;
                     tp = zero_blk;
                     tstep = 0u;
+                    rb_load = SWG_DYN_NONE;
                 }
                 st[0] = end_at;
                 st[1] = fl;
@@ -1265,29 +1276,49 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
         }
         pick_cur = pick_nxt; // the block worked on now was loaded during the previous iteration ...
         pick_nxt = pick;     // ... and the one loaded during this iteration belongs to the leader's current sequence
+        if (EDGES) {
+            rb_cur = rb_nxt;
+            rb_nxt = rb_load;
+            if (rb_load != SWG_DYN_NONE) rb_load += 8u;
+            ec = en;
+            // lanes 0..3 of a group fetch the next block's left edges, one row each
+            const uint32_t bq = quad_bcast(rb_nxt, 0);
+            en = make_int2(0, 0);
+            if (g < 4 && bq != SWG_DYN_NONE && p.edge_in) en = p.edge_in[(size_t)bq + 2u * (uint32_t)g];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             // the leader's token of this row: the residue byte of ITS sequence of the pair, and the flags
             const uint32_t raw = r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
             const uint32_t fresh = __builtin_amdgcn_perm(raw, raw, pick_cur);
+            uint32_t lm = 0u, lb = 0u, fresh_ridx = SWG_DYN_NONE;
+            if (EDGES) {
+                lm = quad_bcast((uint32_t)ec.x, r);
+                lb = quad_bcast((uint32_t)ec.y, r);
+                fresh_ridx = rb_cur != SWG_DYN_NONE ? rb_cur + 2u * (uint32_t)r : SWG_DYN_NONE;
+            }
             int em, eb;
             const int Gs = opaque_uniform(G);
             if (Gs == 16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
-                em = (int)dpp_zero<DPP_ROW_SHR1>((uint32_t)m_out);
-                eb = (int)dpp_zero<DPP_ROW_SHR1>((uint32_t)b_out);
+                em = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, (uint32_t)m_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)m_out));
+                eb = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, (uint32_t)b_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)b_out));
+                if (EDGES) ridx = dpp_keep<DPP_ROW_SHR1>(fresh_ridx, ridx);
             } else {
                 const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
-                const uint32_t u1 = dpp_zero<DPP_WAVE_SHR1>((uint32_t)m_out);
-                const uint32_t u2 = dpp_zero<DPP_WAVE_SHR1>((uint32_t)b_out);
+                const uint32_t u1 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lm, (uint32_t)m_out) : dpp_zero<DPP_WAVE_SHR1>((uint32_t)m_out);
+                const uint32_t u2 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lb, (uint32_t)b_out) : dpp_zero<DPP_WAVE_SHR1>((uint32_t)b_out);
+                const uint32_t u4 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(fresh_ridx, ridx) : 0u;
                 if (Gs == 32) { // lane 32 starts a group too
                     tok = leader ? fresh : u0;
-                    em = leader ? 0 : (int)u1;
-                    eb = leader ? 0 : (int)u2;
+                    em = leader ? (int)lm : (int)u1;
+                    eb = leader ? (int)lb : (int)u2;
+                    if (EDGES) ridx = leader ? fresh_ridx : u4;
                 } else {
                     tok = u0;
                     em = (int)u1;
                     eb = (int)u2;
+                    if (EDGES) ridx = u4;
                 }
             }
             if (r == 0) T0 = tp[0];
@@ -1313,13 +1344,19 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                     if (tail) {
                         const uint32_t seq = st[SWG_DYN_RING + at];
                         const uint32_t sc = __hip_atomic_exchange(st + SWG_DYN_MAXES + at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (seq < p.seq_limit) p.scores[seq] = (int)sc;
+                        if (seq < p.seq_limit) {
+                            if (EDGES) atomicMax(p.scores + seq, (int)sc); // one pass of several
+                            else p.scores[seq] = (int)sc;
+                        }
                     }
                     ++nlast;
                 }
             }
             m_out = e.x;
             b_out = e.y;
+            if (EDGES) {
+                if (tail && ridx != SWG_DYN_NONE && p.edge_out) p.edge_out[ridx] = e;
+            }
         }
         tp += tstep;
         ++blocks;
@@ -1818,12 +1855,15 @@ const DiagVariant *diag_variants(int *n)
 } // namespace
 
 namespace {
-template <int K, int MAXW> void (*q32_kernel())(const SwgDiagQ32Params) { return swg_diag32q_kernel<K, MAXW>; }
 typedef void (*Q32Kernel)(const SwgDiagQ32Params);
+struct Q32Pair {
+    Q32Kernel single, edges;
+};
+template <int K, int MAXW> Q32Pair q32_kernel() { return Q32Pair{swg_diag32q_kernel<K, MAXW, false>, swg_diag32q_kernel<K, MAXW, true>}; }
 // one instantiation per K of the diagonal variants (same order: the variant index is shared)
-const Q32Kernel *q32_kernels()
+const Q32Pair *q32_kernels()
 {
-    static const Q32Kernel v[] = {
+    static const Q32Pair v[] = {
         q32_kernel<24, 16>(), q32_kernel<12, 16>(), q32_kernel<8, 16>(), q32_kernel<16, 16>(), q32_kernel<32, 12>(),
         q32_kernel<6, 16>(),  q32_kernel<10, 16>(), q32_kernel<20, 16>(), q32_kernel<28, 12>(), q32_kernel<4, 16>(),
         q32_kernel<14, 16>(), q32_kernel<18, 16>(), q32_kernel<22, 16>(), q32_kernel<2, 16>(),
@@ -1843,7 +1883,7 @@ size_t swg_diag32q_lds_bytes(int K, int G, int W)
     return (size_t)G * swg_q32_padded_cols(K) * 128u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
 }
 
-hipError_t swg_launch_diag32q(int variant, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream)
+hipError_t swg_launch_diag32q(int variant, bool edges, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream)
 {
     int n;
     const DiagVariant *v = diag_variants(&n);
@@ -1852,7 +1892,7 @@ hipError_t swg_launch_diag32q(int variant, int W, int workgroups, const SwgDiagQ
         return hipErrorInvalidValue;
     const size_t lds = swg_diag32q_lds_bytes(v[variant].info.K, (int)p.G, W);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = q32_kernels()[variant];
+    auto k = edges ? q32_kernels()[variant].edges : q32_kernels()[variant].single;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
