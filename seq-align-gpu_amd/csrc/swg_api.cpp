@@ -614,8 +614,8 @@ static int diag_class_workgroups(const swg_ctx *ctx, const swg_db *db, const Swg
         displaced = (wk.plan[1].workgroups * wk.plan[1].W + pl.W - 1) / pl.W;
     int wgs = std::min(pl.workgroups, capacity - displaced);
     // three wavefronts per SIMD issue as fast as four and leave the scheduler more room: measured
-    // +1.3 % (K=20) to +2.8 % (K=23) on a uniform database, -0.3 % at K=16
-    if (wk.n_classes == 1 && pl.K >= 20 && pl.W == 4 && per_cu == 4) wgs = std::min(wgs, ctx->n_cu * 3);
+    // (round 2 kernels, uniform database, tools/sweeps/r2_occ.sh) +1.3 % at K=16, level at K=20 and 23, +1.1 % at K=24
+    if (wk.n_classes == 1 && pl.K >= 16 && pl.W == 4 && per_cu == 4) wgs = std::min(wgs, ctx->n_cu * 3);
     return std::max(1, wgs);
 }
 
