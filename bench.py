@@ -291,7 +291,9 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
         if os.path.exists(a.traffic_json):
             try:
                 tj = json.load(open(a.traffic_json))
-                traffic = tj.get("config%d" % cnum, {}).get("hbm_bytes_per_launch")
+                # (counters are collected per configuration as bench.py --config C runs it; the whole-database form
+                # of config 4 has no measurement of its own: null rather than the share's figure)
+                traffic = tj.get("config%d%s" % (cnum, "_whole" if sharded else ""), {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # The binding roof is integer VALU issue, reported beside the (by construction tiny) HBM
