@@ -102,6 +102,7 @@ def parse_args():
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="one GPU: skip the whole 10M-sequence config-4 database (the N = 1 point of the scaling curve)")
     ap.add_argument("--only-headline", action="store_true", help="one GPU: the headline configuration alone")
+    ap.add_argument("--max-len", type=int, default=0, help="diagnostic: clamp the sequence lengths here (default 5000)")
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
@@ -202,6 +203,8 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
             flat, off, _ = swg.synth_db(seed, n, query=q, fraction=cfg["similar"], subst=0.05)
         elif a.uniform_len:
             flat, off = swg.synth_db(seed, n, min_len=a.uniform_len, max_len=a.uniform_len)
+        elif a.max_len:
+            flat, off = swg.synth_db(seed, n, max_len=a.max_len)
         else:
             flat, off = swg.synth_db(seed, n)
         index = None

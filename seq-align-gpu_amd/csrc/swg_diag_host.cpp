@@ -174,6 +174,9 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     streams0 = (streams0 + spw - 1) / spw * spw;
                     if (split) {
                         if (split == 3 && opt_long_split > 0) continue;
+                        // experiment switch long_group=16: only the bulk's own geometry as the long class
+                        if (g_swg_long_group == 16 && split != 2) continue;
+                        if (g_swg_long_group != 16 && g_swg_long_group > 0 && split == 2) continue;
                         const double frac = split == 3 ? 0.6 : 0.33;
                         uint64_t thr = opt_long_split > 0 ? (uint64_t)opt_long_split
                                                           : (uint64_t)(frac * rows_all / (double)streams0);
