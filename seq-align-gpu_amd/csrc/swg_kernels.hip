@@ -6,53 +6,50 @@
 // against every sequence of a packed database -- i.e. the reference's whole
 // timed region, src/alignment_cmdline.c:503-509, not one 16-lane call.
 //
-// How (nothing here follows the reference's AVX2 code):
+// How (nothing here follows the reference's AVX2 code).  Three families of fill kernels live in this
+// file; the host planner (swg_diag_host.cpp, swg_api.cpp) picks one per search:
 //
-//  * Inter-sequence parallelism like the reference's 16 int16 lanes, but at
-//    wave64 width: lane l of a wavefront owns database sequences l and l+64 of
-//    a 128-sequence bin, one in each int16 half of its VGPRs (v_pk_* packed
-//    math), so one wavefront advances 128 alignments per instruction.
+//  * The lane-group fill with a work queue (swg_diag_dyn_kernel, the default): G = 16, 32 or 64
+//    lanes of a wavefront share ONE pair of database sequences, one in each int16 half of their
+//    VGPRs (v_pk_* packed math).  Lane l of the group owns K query columns (3 VGPRs per column:
+//    M = max(H,A,B), G = M - |go| floored, A) and runs one database row behind lane l-1, so the
+//    group sweeps the DP matrix as an anti-diagonal wavefront; the right edge (M, B) of a lane's
+//    strip reaches its neighbour by one DPP row_shr/wave_shr move per row, never through memory.
+//    Groups take pairs (longest first) from sharded atomic counters and stream them back to back:
+//    the row tokens of the next pair follow the last row of the previous one, so the diagonal
+//    pipeline never drains.  Queries longer than G*K columns take several passes with the last
+//    lane's edge kept in a per-pair HBM buffer (8 B per row per pair per pass).
+//    swg_diag_kernel is the same engine with a fixed stream of pairs per group (option dynamic = 0).
 //
-//  * A wavefront keeps K query columns of DP state in registers (3 VGPRs per
-//    column: M = max(H,A,B), G = M - |go| floored, A) and walks down the
-//    database rows.  W wavefronts of a workgroup form a SYSTOLIC array over the
-//    query: wave w owns columns [w*K, (w+1)*K) and runs one row-block (4 rows)
-//    behind wave w-1.  The only values that cross a wave boundary are the right
-//    edge (M, B) of each row; they are handed over through a double-buffered
-//    LDS ring, one s_barrier per row-block.  Nothing of the DP state ever goes
-//    to HBM for queries up to W*K columns; longer queries take several passes,
-//    the last wave spilling its edge to a small per-workgroup scratch that wave
-//    0 re-reads in the next pass (8 B per row per 128 sequences per pass).
+//  * The same engine in 32-bit cells (swg_diag32q_kernel): one sequence per group, used when scores
+//    may pass 16 bits, for re-scoring flagged sequences and when forced; and the exact three-state
+//    recurrence for positive gap scores (swg_diag32_kernel).
 //
-//  * The query profile (substitution scores of every query column against all
-//    32 residue indices) lives in LDS in [4-column chunk][32 residues][4] int16
-//    order: a chunk is exactly one 256-byte LDS bank row and a lane's read
-//    address is chunk*256 + residue*8, so the 32 possible addresses of one
-//    ds_read_b64 hit 32 distinct 8-byte bank slots (or broadcast): the per-lane
-//    gather that dominates the reference (scoring_lookup, src/alignment.c:31-44)
-//    is bank-conflict-free and costs one LDS read per 8 cells.
+//  * The systolic fill (swg_fill_kernel): a wavefront owns 128 whole sequences of a bin and W waves
+//    of a workgroup split the query's columns, edges crossing through an LDS ring.  It needs no
+//    per-pair tokens and serves swg_fill_batches16 (the reference-shaped 16-lane batches) and
+//    option engine = 1.
 //
-//  * Work distribution: bins are sorted longest-first and handed out through an
-//    atomic work counter; a workgroup streams bins back-to-back through its
-//    pipeline without draining it.
+//  * The query profile (substitution scores of every query column against all 32 residue indices)
+//    lives in LDS in [4-column chunk][32 residues][4] int16 order: a chunk is exactly one 256-byte
+//    LDS bank row and a lane's read address is chunk*256 + residue*8 (rows XOR-swizzled by lane in
+//    the lane-group kernels, so lanes that read the same residue still spread over the banks).
+//    The per-lane gather that dominates the reference (scoring_lookup, src/alignment.c:31-44)
+//    costs one ds_read_b64 per 8 cells and its address one SDWA xor per row.
 //
-//  * No MFMA: the recurrence is integer max/add with a loop-carried dependency.
+//  * No MFMA: the recurrence is integer max/add with a loop-carried dependency.  The bound is VALU
+//    issue: 10 packed instructions per 2 cells.
 //
 // int16 fast path (gap_open <= 0 and gap_extend <= 0, the normal case): with
 // M = max(H,A,B) the recurrence collapses to
 //     A' = max(M_up - |go|, A_up - |ge|)   B' = max(M_left - |go|, B_left - |ge|)
 //     M' = max(M_diag + s, A', B')         all floored at 0
 // which is value-identical to the reference's (max distributes over +const and
-// go <= ge makes the extra transitions redundant; DESIGN.md gives the proof),
-// 11 packed VALU instructions per two cells.  Floors come for free from
-// unsigned saturating subtracts (v_pk_sub_u16 clamp); the diagonal add is a
-// signed saturating add (v_pk_add_i16 clamp), so a score that reaches 32767
-// sticks there and the sequence is flagged for the int32 path.  The reference
-// wraps silently instead.
-//
-// int32 exact path: the reference's recurrence term by term (valid for any sign
-// of the gap scores), one sequence per lane, used for re-scoring saturated
-// sequences, for unusual gap scores, and when forced.
+// go <= ge makes the extra transitions redundant; DESIGN.md gives the proof).
+// Floors come for free from unsigned saturating subtracts (v_pk_sub_u16 clamp); the
+// diagonal add is a signed saturating add (v_pk_add_i16 clamp), so a score that reaches
+// 32767 sticks there and the sequence is flagged for a wider path (the biased "wide"
+// variant to 65535, then 32-bit cells).  The reference wraps silently instead.
 #include "swg_internal.h"
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
