@@ -27,7 +27,16 @@ ARCH = "gfx950"
 # pairs into ds_read2_b64, which is banked modulo 32 dwords and runs at half the
 # bytes per clock (MI355X_MICROARCH.md, LDS table): keep it off for device code.
 # (The host half of the compile prints a harmless "not a recognized feature".)
-DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+#
+# Machine scheduler: the AMDGPU back end's "max-ilp" strategy instead of its default (maximum
+# occupancy).  The fill kernels are bounded by their launch bounds to the occupancy they run at anyway;
+# within that budget the default strategy left the K=32 multi-pass kernel 14-19 registers short
+# (spills inside the row loop), max-ilp fits it in 158 with no spill.  Measured on one box, same
+# source: config 4 6933 -> 7178 GCUPS, config 5 6505 -> 6512, config 2 6284 -> 6283, config 3
+# 7150 -> 7180 (profiles/r02_sched_strategy_ab.txt).  The option is read by the AMDGPU target
+# only; the host half of the compile ignores it.
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt",
+                "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 HIP_SOURCES = ["swg_kernels.hip", "swg_trace.hip", "swg_api.cpp", "swg_group.cpp"]
 CXX_SOURCES = ["swg_pack.cpp", "swg_diag_host.cpp"]  # host-only C++, OpenMP via g++

@@ -192,6 +192,11 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         ctx->opt_wide = value != 0;
     } else if (!strcmp(key, "long_helps")) {
         ctx->opt_long_helps = value != 0;
+    } else if (!strcmp(key, "segment_blocks")) {
+        // (tests: the multi-pass fill cuts its launches into segments of at most this many token blocks)
+        if (value < 0 || value > (long)SWG_DYN_SEG_BLOCKS)
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "segment_blocks must be 0 (default) .. 2^26-64");
+        ctx->opt_seg_blocks = value ? (uint32_t)value : SWG_DYN_SEG_BLOCKS;
     } else if (!strcmp(key, "work_queue")) {
         ctx->opt_dynamic = value != 0;
     } else if (!strcmp(key, "prio_share")) {
@@ -743,14 +748,46 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             const bool edges = pl.npass > 1 || pl.wide != 0;
             const size_t slice = (size_t)pl.G * swg_diag_padded_cols(pl.K) * 64;
             hipStream_t qs = c == 1 ? ctx->stream2 : s;
+            // The form with edges addresses a launch's tokens and edges by 32-bit offsets: pairs whose
+            // token blocks span more than SWG_DYN_SEG_BLOCKS go in several launches per pass, each over a
+            // run of consecutive pairs (a segment).  Normally there is one, the whole token buffer.
+            std::vector<std::pair<uint32_t, uint32_t>> segs; // pair ranges
+            if (!edges || T.total_blocks <= ctx->opt_seg_blocks) {
+                segs.push_back(std::make_pair(q.q_begin, q.q_end));
+                q.seg_origin = 0;
+                q.seg_blocks = (uint32_t)std::min<uint64_t>(T.total_blocks, ctx->opt_seg_blocks);
+            } else {
+                const std::vector<uint32_t> &pre = T.pair_blocks_prefix;
+                for (uint32_t b = q.q_begin; b < q.q_end;) {
+                    const uint64_t limit = (uint64_t)pre[b] + ctx->opt_seg_blocks;
+                    const uint32_t e = (uint32_t)(std::upper_bound(pre.begin() + b, pre.begin() + q.q_end + 1, limit,
+                                                                   [](uint64_t v, uint32_t x) { return v < (uint64_t)x; }) -
+                                                  pre.begin()) - 1u;
+                    if (e <= b) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "a pair of sequences too long for the multi-pass fill");
+                    segs.push_back(std::make_pair(b, e));
+                    b = e;
+                }
+                q.q2_begin = q.q2_end = 0; // (the other class's pairs lie outside a segment)
+                q.queue2 = nullptr;
+            }
+            bool first_launch = true;
             for (int pass = 0; pass < pl.npass; ++pass) {
                 // one launch per pass: the kernel boundary is what lets any lane group take any pair
-                if (pass > 0)
-                    HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, qs));
                 q.profile = ctx->d_profile[diag_profile_slot(pl, c)] + (size_t)pass * slice;
                 q.edge_in = pass > 0 ? T.d_edge[(pass - 1) & 1] : nullptr;
                 q.edge_out = pass + 1 < pl.npass ? T.d_edge[pass & 1] : nullptr;
-                HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pl.wide != 0, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
+                for (const std::pair<uint32_t, uint32_t> &sg : segs) {
+                    if (!first_launch)
+                        HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, qs));
+                    first_launch = false;
+                    q.q_begin = sg.first;
+                    q.q_end = sg.second;
+                    if (segs.size() > 1) {
+                        q.seg_origin = T.pair_blocks_prefix[sg.first];
+                        q.seg_blocks = T.pair_blocks_prefix[sg.second] - q.seg_origin;
+                    }
+                    HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pl.wide != 0, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
+                }
             }
             continue;
         }

@@ -293,7 +293,7 @@ int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, lon
 // blocks.  The device builds the same image from the resident residue bytes
 // (swg_build_tokens_kernel); this is its host restatement, used by the fixed-stream layout and by
 // the tests that compare the two.
-static const uint32_t kTokReset = 0x10000u, kTokLast = 0x20000u;
+static const uint32_t kTokReset = SWG_TOK_RESET, kTokLast = SWG_TOK_LAST;
 static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint32_t *t)
 {
     const size_t n_slots = (size_t)db->n_bins * SWG_BIN;

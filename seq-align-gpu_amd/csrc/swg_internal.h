@@ -51,10 +51,17 @@ struct SwgDiagParams {
     uint64_t *trace;                 // diagnostics (SWG_TRACE): per wavefront {start, end, blocks}, or null
 };
 
-// The same fill with pairs handed out by device-wide counters (single pass only).
+// Row tokens of the lane-group kernels: byte 0 = residue of the pair's first sequence << 3, byte 1 = of
+// its second, then flags.
+#define SWG_TOK_RESET 0x10000u
+#define SWG_TOK_LAST 0x20000u
+#define SWG_TOK_IDLE 0x40000u // first row after a lane group's last pair (several passes only): the tail lane stops storing edges
+
+// The same fill with pairs handed out by device-wide counters.
 #define SWG_DYN_SHARDS 8u        // counters per range; shard c hands out pairs begin + c + 8k
 #define SWG_DYN_SHARD_STRIDE 32u // dwords between counters: one 128-byte line each
 #define SWG_DYN_SIMD_SLOTS 8192u // wavefront-rank counters, one per physical SIMD (xcc, se, sh, cu, simd)
+#define SWG_DYN_SEG_BLOCKS ((1u << 26) - 64u) // token blocks one launch with edges can address (see swg_diag_dyn_kernel)
 struct SwgDiagDynParams {
     const uint4 *tok;         // pair-major token blocks (4 rows, one 32-bit token each), longest pair first
     uint32_t zero_block;      // index of a block of zeros in tok (padding rows for lanes that feed no pair)
@@ -73,6 +80,10 @@ struct SwgDiagDynParams {
     uint32_t *simd_ranks;     // [SWG_DYN_SIMD_SLOTS] zero before the search
     const uint2 *edge_in;     // one pass of several: (M,B) left edge per row from the previous pass (null: first)
     uint2 *edge_out;          // ... right edge per row for the next pass (null: last)
+    // ... of token blocks [seg_origin, seg_origin + seg_blocks): a launch with edges addresses tokens and
+    // edges by 32-bit byte offsets from the segment's start, so seg_blocks <= SWG_DYN_SEG_BLOCKS and the
+    // pairs [q_begin, q_end) lie inside the segment
+    uint32_t seg_origin, seg_blocks;
     uint32_t turn_levels;     // priorities the other wavefronts rotate through: 3 beside a long class, else 4
     uint64_t *trace;          // diagnostics (SWG_TRACE) or null
     // several queries in one launch (swg_search_multi): grid.y = query; workgroup row y reads profile +

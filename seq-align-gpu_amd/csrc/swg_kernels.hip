@@ -51,6 +51,7 @@
 // 32767 sticks there and the sequence is flagged for a wider path (the biased "wide"
 // variant to 65535, then 32-bit cells).  The reference wraps silently instead.
 #include "swg_internal.h"
+#include <type_traits>
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -91,6 +92,12 @@ DEVINL int2 lds_read_i2(uint32_t addr)
 {
     const i32x2 v = *reinterpret_cast<__attribute__((address_space(3))) const i32x2 *>((uintptr_t)addr);
     return make_int2(v.x, v.y);
+}
+// buffer resources (raw, no stride): loads beyond num_records return zero, stores beyond it are dropped
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+DEVINL rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 // 32-bit LDS address of a __shared__ array
 #define SWG_LDS_ADDRESS(arr) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(arr))
@@ -443,8 +450,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 // whose components are the rows (nothing to extract).  Costs 4 bytes per pair-row of HBM
 // instead of 2 -- irrelevant at 0.2 % of the HBM roofline -- and saves five VALU instructions
 // per lane-row.
-#define SWG_TOK_RESET 0x10000u
-#define SWG_TOK_LAST 0x20000u
 #define DPP_ROW_SHR1 0x111
 #define DPP_WAVE_SHR1 0x138
 
@@ -765,6 +770,15 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 #endif
 #define SWG_DYN_HOT 4u     // current pair is long: raised priority
 #define SWG_DYN_SECOND 8u  // on the second range
+#define SWG_DYN_IDLING 16u // EDGES: out of pairs, the block with the idle row is on its way
+#define SWG_DYN_KEEP 0xFFFFFFFEu
+// EDGES: byte offsets of lanes with nothing to load or store.  With at most SWG_DYN_SEG_BLOCKS < 2^26
+// blocks per launch the token resource is < 2^30 bytes and the edge resources < 2^31; a parked offset
+// moves like the others (16 bytes per block, the tail's 32) for at most that many blocks, so it stays
+// in [2^30, 2^31) -- twice that in [2^31, 2^32) -- and the tail's in [2^31, 2^32): out of bounds
+// wherever they are used.
+#define SWG_OFF_PARKED 0x40000000u
+#define SWG_OFF_PARKED_TAIL 0x80000000u
 #define SWG_DYN_NONE 0xFFFFFFFFu
 // flags bits 8..: shards of the current range found empty so far
 
@@ -785,10 +799,18 @@ DEVINL uint32_t quad_bcast(uint32_t x, int r)
 // comes from the previous pass's launch (edge_in, null in the first pass) and the right edge goes
 // to the next one (edge_out, null in the last), both indexed by the row's position in the pair-major
 // token order, so any lane group can take any pair in any pass; the kernel boundary is the
-// synchronisation.  Scores are the maximum over the passes.  Costs seven instructions per row: the
-// row index travels with the token; the first four lanes of a group each prefetch one row's edge of
-// the next block and hand it to the leader with a quad broadcast; the tail lane stores its edge
-// every row.
+// synchronisation.  Scores are the maximum over the passes.  Nothing of it is paid per row beyond two
+// quad broadcasts and the store itself, and it takes few registers (at K=32 there are none to spare):
+// tokens and edges are addressed through buffer resources by ONE 32-bit byte offset per lane.  In
+// lanes 0..3 of a group it is the token offset of row g of the block being loaded -- the leader's own
+// tokens; twice that is the offset of the row's left edge, which each of the four lanes fetches for
+// the leader to pick up with a quad broadcast --; in the tail lane it is where the right edges of its
+// current block go.  Offsets outside a resource read as zero and store nothing, which is what lanes
+// with nothing to do want: they sit in a range that is out of bounds for all three resources and stays
+// so for as many blocks as a launch can have (hence SWG_DYN_SEG_BLOCKS).  The tail lane sets its offset
+// when a pair's first reset row reaches it (always at unrolled row 3: the tail is G-1 = 3 mod 4 rows
+// behind the leader) from the pair ring, and parks it when the row flagged IDLE -- sent once by a
+// leader that finds the queue empty -- reaches it.
 // WIDE: scores to 65535 (see CellsDiag); needs EDGES (a query that can pass 32767 is long).
 template <int K, int MAXW, bool EDGES = false, bool WIDE = false>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDynParams p)
@@ -830,24 +852,23 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     uint32_t tok = 0u, m_out = Z, b_out = Z;
     uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
     uint32_t nlast = 0u;               // last rows this lane has seen = position of its pair in the group's rings
-    // Tokens, single pass: T0..T3 are the rows of the block being worked on.  Each is re-loaded with the
-    // same row of the NEXT block right after its use (one block of time for the load to land), from the
-    // per-lane pointer tp: the leader's runs through its pair's blocks, everybody else's -- and an idle
-    // leader's -- stays on a block of zeros (padding rows).  No register copies between blocks, nothing
-    // to clear: nine VALU instructions fewer per block than loading whole blocks into cur / nxt, which
-    // the EDGES form keeps (it needs the block index anyway, and at K=32 it has no register to spare:
-    // the pointer form spilled inside the loop and ran 1 % slower there).
+    // Tokens: T0..T3 are the rows of the block being worked on.  Each is re-loaded with the same row of
+    // the NEXT block right after its use (one block of time for the load to land), from the per-lane
+    // pointer tp: the leader's runs through its pair's blocks, everybody else's -- and an idle leader's --
+    // stays on a block of zeros (padding rows).  No register copies between blocks, nothing to clear.
     uint32_t T0 = 0u, T1 = 0u, T2 = 0u, T3 = 0u;
     const uint32_t *const zero_blk = reinterpret_cast<const uint32_t *>(p.tok + p.zero_block);
     const uint32_t *tp = zero_blk;
     uint32_t tstep = 0u;         // dwords tp advances per block: 4 while the leader feeds a pair
-    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
-    uint4 cur = none, nxt = none; // EDGES: the block being worked on, the next one
-    uint32_t bi = SWG_DYN_NONE;   // EDGES: leader lane: next token block of the pair it feeds (none: idle)
-    // EDGES: block index of cur / nxt (leader), row index travelling with the token, left edges of
-    // the current / next block (lanes 0..3 of a group, one row each)
-    uint32_t bcur = SWG_DYN_NONE, bnxt = SWG_DYN_NONE, ridx = SWG_DYN_NONE;
+    // EDGES: left edges of the current / next block (lanes 0..3 of a group, one row each), and the lane's
+    // byte offset into the segment's tokens (lanes 0..3; times two: into the incoming edges) or into
+    // the outgoing edges (tail lane)
     uint2 ec = make_uint2(Z, Z), en = make_uint2(Z, Z);
+    uint32_t off = tail ? SWG_OFF_PARKED_TAIL : SWG_OFF_PARKED;
+    const uint64_t tails = __builtin_amdgcn_ballot_w64(tail);
+    const rsrc_t tokR = make_rsrc(p.tok + p.seg_origin, EDGES ? p.seg_blocks * 16u : 0u);
+    const rsrc_t einR = make_rsrc(p.edge_in + (size_t)p.seg_origin * 4u, EDGES && p.edge_in ? p.seg_blocks * 32u : 0u);
+    const rsrc_t eoutR = make_rsrc(p.edge_out + (size_t)p.seg_origin * 4u, EDGES && p.edge_out ? p.seg_blocks * 32u : 0u);
     // wave-uniform: block counter, the count at which the next pair runs out (none: all leaders idle)
     uint32_t blocks = 0u, next_event = 0u, drain = 0u, events = 0u;
     uint64_t event_ticks = 0ull; // diagnostics
@@ -882,6 +903,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         else __builtin_amdgcn_s_setprio(3);
     };
 
+    // The main loop exists twice, for groups of 16 lanes (edges handed over by row_shr) and for wider ones
+    // (wave_shr and a select at lane 32): a run-time test of G inside the row makes the register allocator's
+    // job harder than it is.
+    auto main_loop = [&](auto g16_tag) {
+    constexpr bool G16 = decltype(g16_tag)::value;
     for (;;) {
         if (blocks == next_event) {
             // some pair has run out (or this is the start): its leader takes the next one
@@ -891,6 +917,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             uint32_t *st = record();
             uint32_t end_at = st[0];
             uint32_t fl = st[1];
+            uint32_t efirst = SWG_DYN_KEEP; // EDGES: first block of the pair taken in this event (none: gone idle)
             if (leader && end_at == blocks) {
                 // The queue is SWG_DYN_SHARDS counters, shard c handing out pairs begin+c, begin+c+S, ..
                 // (one counter for everybody saturates the atomic unit of its memory channel at ~16
@@ -899,6 +926,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 bool second = (fl & SWG_DYN_SECOND) != 0u;
                 uint32_t tried = fl >> 8;
                 uint32_t nq = SWG_DYN_NONE;
+                if (EDGES && (fl & SWG_DYN_IDLING)) tried = SWG_DYN_SHARDS, second = true; // (the queues were empty a block ago)
                 for (;;) {
                     if (tried >= SWG_DYN_SHARDS) {
                         if (second || p.q2_end <= p.q2_begin) break;
@@ -914,12 +942,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     }
                     ++tried;
                 }
+                const bool idling = (fl & SWG_DYN_IDLING) != 0u;
                 fl = (second ? SWG_DYN_SECOND : 0u) | (tried << 8);
                 if (nq != SWG_DYN_NONE) {
                     const uint32_t first = p.pair_off[nq];
                     const uint32_t len = p.pair_off[nq + 1u] - first;
                     if (EDGES) {
-                        bi = first;
+                        efirst = first;
                     } else {
                         tp = reinterpret_cast<const uint32_t *>(p.tok + first);
                         tstep = 4u;
@@ -929,14 +958,28 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     st[SWG_DYN_RING + (pushed & (SWG_DYN_RING - 1u))] = nq;
                     st[2] = pushed + 1u;
                     if (len >= (second ? p.prio_blocks2 : p.prio_blocks)) fl |= SWG_DYN_HOT;
+                } else if (EDGES && !idling) {
+                    // out of pairs: this block's loads bring zeros; the next event flags their first row
+                    end_at = blocks + 1u;
+                    efirst = SWG_DYN_NONE;
+                    fl |= SWG_DYN_IDLING;
+                } else if (EDGES) {
+                    end_at = SWG_DYN_NONE;
+                    T0 = SWG_TOK_IDLE; // (loaded as zero during the last block)
+                    fl |= SWG_DYN_IDLING;
                 } else {
                     end_at = SWG_DYN_NONE;
                     tp = zero_blk;
                     tstep = 0u;
-                    bi = SWG_DYN_NONE;
                 }
                 st[0] = end_at;
                 st[1] = fl;
+            }
+            if (EDGES) {
+                // the first four lanes follow their leader: row g of the new pair's first block, or parked
+                const uint32_t ef = quad_bcast(efirst, 0);
+                if (g < 4 && ef != SWG_DYN_KEEP)
+                    off = ef != SWG_DYN_NONE ? (ef - p.seg_origin) * 16u + (uint32_t)g * 4u : SWG_OFF_PARKED;
             }
             next_event = SWG_DYN_NONE;
             for (int i = 0; i < 64; i += G)
@@ -952,57 +995,50 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             drain += 4u;
         }
         if (EDGES) {
-            cur = nxt;
-            nxt = none;
-            bcur = bnxt;
-            bnxt = bi;
-            ec = en;
-            if (bi != SWG_DYN_NONE) {
-                nxt = p.tok[bi];
-                ++bi;
-            }
-        }
-        if (EDGES) {
             // lanes 0..3 of a group fetch the next block's left edges, one row each
-            const uint32_t bq = quad_bcast(bnxt, 0);
-            en = make_uint2(Z, Z);
-            if (g < 4 && bq != SWG_DYN_NONE && p.edge_in) en = p.edge_in[(size_t)bq * 4u + (uint32_t)g];
+            ec = en;
+            if (p.edge_in) { // (the first pass has none: the edges stay zero)
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(einR, off * 2u, 0, 0);
+                en = make_uint2(v.x, v.y);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t fresh = EDGES ? block_row(cur, r) : r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
-            uint32_t lm = Z, lb = Z, fresh_ridx = SWG_DYN_NONE;
+            const uint32_t fresh = r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
+            uint32_t lm = Z, lb = Z;
             if (EDGES) {
                 lm = quad_bcast(ec.x, r);
                 lb = quad_bcast(ec.y, r);
-                fresh_ridx = bcur != SWG_DYN_NONE ? bcur * 4u + (uint32_t)r : SWG_DYN_NONE;
             }
             uint32_t em, eb;
-            const int Gs = opaque_uniform(G);
-            if (Gs == 16) {
+            const int Gs = G16 ? 16 : opaque_uniform(G);
+            if (G16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
                 em = EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, m_out) : dpp_zero<DPP_ROW_SHR1>(m_out);
                 eb = EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, b_out) : dpp_zero<DPP_ROW_SHR1>(b_out);
-                if (EDGES) ridx = dpp_keep<DPP_ROW_SHR1>(fresh_ridx, ridx);
             } else {
                 const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
                 const uint32_t u1 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lm, m_out) : dpp_zero<DPP_WAVE_SHR1>(m_out);
                 const uint32_t u2 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lb, b_out) : dpp_zero<DPP_WAVE_SHR1>(b_out);
-                const uint32_t u4 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(fresh_ridx, ridx) : 0u;
                 if (Gs == 32) { // lane 32 starts a group too
                     tok = leader ? fresh : u0;
                     em = leader ? lm : u1;
                     eb = leader ? lb : u2;
-                    if (EDGES) ridx = leader ? fresh_ridx : u4;
                 } else {
                     tok = u0;
                     em = u1;
                     eb = u2;
-                    if (EDGES) ridx = u4;
                 }
             }
             // this row of the next block (the register is free: its value went into the DPP move above)
-            if (!EDGES) {
+            if (EDGES) {
+                const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(tokR, off + (uint32_t)r * 4u, 0, 0);
+                if (r == 0) T0 = t;
+                else if (r == 1) T1 = t;
+                else if (r == 2) T2 = t;
+                else T3 = t;
+                if (r == 3) off += tail ? 32u : 16u; // (the tail lane is 3 (mod 4) rows behind: its blocks begin here)
+            } else {
                 if (r == 0) T0 = tp[0];
                 else if (r == 1) T1 = tp[1];
                 else if (r == 2) T2 = tp[2];
@@ -1022,6 +1058,16 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     cells.best &= ~fm;
                     go_v |= fm;
                     ge_v |= fm;
+                }
+                if (EDGES && r == 3 && p.edge_out) {
+                    // a pair's first row at the tail lane: its edges go to the pair's rows from here on
+                    // (the pair is the next one of the ring: every earlier one has had its last row);
+                    // the idle row: nowhere
+                    if (tail && (tok & SWG_TOK_RESET) != 0u) {
+                        const uint32_t pr = record()[SWG_DYN_RING + (nlast & (SWG_DYN_RING - 1u))];
+                        off = (p.pair_off[pr] - p.seg_origin) * 32u;
+                    }
+                    if (tail && (tok & SWG_TOK_IDLE) != 0u) off = SWG_OFF_PARKED_TAIL;
                 }
             }
             const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(prof_addr<0>(base, tok), prof_addr<1>(base, tok),
@@ -1060,13 +1106,17 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             b_out = e.y;
             if (EDGES) {
                 // the tail lane's row is the pass's right edge (L2 gathers a pair's consecutive rows)
-                if (tail && ridx != SWG_DYN_NONE && p.edge_out) p.edge_out[ridx] = e;
+                if (__builtin_expect(__builtin_amdgcn_inverse_ballot_w64(tails), 1))
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{e.x, e.y}, eoutR, off + (uint32_t)((r + 1) & 3) * 8u, 0, 0);
             }
         }
         if (!EDGES) tp += tstep;
         ++blocks;
         if (!hot && (blocks & (SWG_DYN_TURN_EVERY - 1u)) == 0u) take_turn();
     }
+    };
+    if (G == 16) main_loop(std::true_type());
+    else main_loop(std::false_type());
     if (p.stamps && lane == 0) atomicMax(p.stamps + 1, (unsigned long long)wall_clock64()); // latest end
     if (p.trace && lane == 0) {
         uint64_t *t = p.trace + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * W + w) * 4u;
@@ -1837,6 +1887,9 @@ template <int K, int MAXW> DiagVariant make_diag()
 }
 const DiagVariant *diag_variants(int *n)
 {
+#ifdef SWG_PROBE_VARIANT // (ISA experiments on one instantiation: tools/probe_isa.sh)
+    static const DiagVariant v[] = {make_diag<SWG_PROBE_VARIANT>()};
+#else
     static const DiagVariant v[] = {
         make_diag<24, 16>(), make_diag<12, 16>(), make_diag<8, 16>(), make_diag<16, 16>(), make_diag<32, 12>(),
         make_diag<6, 16>(),  make_diag<10, 16>(), make_diag<20, 16>(), make_diag<28, 12>(), make_diag<4, 16>(),
@@ -1846,6 +1899,7 @@ const DiagVariant *diag_variants(int *n)
         make_diag<29, 12>(), make_diag<27, 12>(), make_diag<25, 12>(), make_diag<30, 12>(), make_diag<26, 12>(),
         make_diag<5, 16>(), make_diag<3, 16>(),
     };
+#endif
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
 }
@@ -1860,6 +1914,9 @@ template <int K, int MAXW> Q32Pair q32_kernel() { return Q32Pair{swg_diag32q_ker
 // one instantiation per K of the diagonal variants (same order: the variant index is shared)
 const Q32Pair *q32_kernels()
 {
+#ifdef SWG_PROBE_VARIANT
+    static const Q32Pair v[] = {q32_kernel<SWG_PROBE_VARIANT>()};
+#else
     static const Q32Pair v[] = {
         q32_kernel<24, 16>(), q32_kernel<12, 16>(), q32_kernel<8, 16>(), q32_kernel<16, 16>(), q32_kernel<32, 12>(),
         q32_kernel<6, 16>(),  q32_kernel<10, 16>(), q32_kernel<20, 16>(), q32_kernel<28, 12>(), q32_kernel<4, 16>(),
@@ -1869,6 +1926,7 @@ const Q32Pair *q32_kernels()
         q32_kernel<29, 12>(), q32_kernel<27, 12>(), q32_kernel<25, 12>(), q32_kernel<30, 12>(), q32_kernel<26, 12>(),
         q32_kernel<5, 16>(), q32_kernel<3, 16>(),
     };
+#endif
     return v;
 }
 } // namespace

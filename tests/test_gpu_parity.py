@@ -15,7 +15,7 @@ def _setup(ctx, g):
     _reset_options(ctx)
 
 
-OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups")
+OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups", "segment_blocks")
 DEFAULT_ON = ("work_queue", "wide16")
 DEFAULT_OFF = ("long_helps",)
 
@@ -573,7 +573,12 @@ def test_multipass_through_the_work_queue(swg, ctx, orc):
                  {"cols_per_wave": 12, "group_lanes": 32, "max_waves": 8},
                  {"cols_per_wave": 8, "group_lanes": 64, "max_waves": 4},
                  {"cols_per_wave": 32, "group_lanes": 16, "max_waves": 4},
-                 {"cols_per_wave": 6, "group_lanes": 16, "max_waves": 4}):
+                 {"cols_per_wave": 6, "group_lanes": 16, "max_waves": 4},
+                 # launches cut into segments of consecutive pairs (what a database of more than 2^26
+                 # token blocks gets), also with the long pairs as their own class
+                 {"cols_per_wave": 32, "group_lanes": 16, "max_waves": 4, "segment_blocks": 300},
+                 {"cols_per_wave": 12, "group_lanes": 32, "max_waves": 8, "segment_blocks": 150, "long_split": 1},
+                 {"cols_per_wave": 8, "group_lanes": 64, "max_waves": 4, "segment_blocks": 200}):
         _reset_options(ctx)
         ctx.set_option("engine", 2)
         for k, v in opts.items():
@@ -597,7 +602,8 @@ def test_multipass_through_the_work_queue(swg, ctx, orc):
     want = orc.score_db(q, flat, off, sc.table(), -2, -1)
     ctx.set_scoring(sc, -2, -1)
     ctx.set_query(q)
-    for opts in ({"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4}, {"cols_per_wave": 6, "group_lanes": 64, "max_waves": 4}):
+    for opts in ({"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4}, {"cols_per_wave": 6, "group_lanes": 64, "max_waves": 4},
+                 {"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4, "segment_blocks": 800}):
         _reset_options(ctx)
         ctx.set_option("engine", 2)
         for k, v in opts.items():

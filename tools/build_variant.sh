@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 P=/root/repo/seq-align-gpu_amd
 for src in swg_kernels.hip swg_api.cpp; do
-  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c -Xclang -target-feature -Xclang -load-store-opt "$@" \
+  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c -Xclang -target-feature -Xclang -load-store-opt -mllvm -amdgpu-sched-strategy=max-ilp "$@" \
     -o /tmp/${src}_$name.o -x hip $P/csrc/$src 2>&1 | grep -v "recognized feature" || true
 done
 objs=$(ls $P/build/*.o | grep -v "swg_kernels\|swg_api")

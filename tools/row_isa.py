@@ -1,6 +1,6 @@
 """Static instruction mix of one database row of the work-queue fill kernel, from the built library.
 
-    python tools/row_isa.py [K] > profiles/rNN_kK_row_isa.txt
+    python tools/row_isa.py [K] [edges] [wide] > profiles/rNN_kK_row_isa.txt
 
 Extracts the gfx950 code object from seq-align-gpu_amd/libswg.so (llvm-objdump --offloading),
 disassembles swg_diag_dyn_kernel<K,16,false,false> and classifies the instructions of the first
@@ -11,6 +11,8 @@ import collections, glob, os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 23
+EDGES = int("edges" in sys.argv[2:])     # the several-pass variant (edge columns through HBM)
+WIDE = int("wide" in sys.argv[2:])       # the biased variant that counts to 65535
 tmp = tempfile.mkdtemp()
 lib = os.path.join(tmp, "libswg.so")
 shutil.copy(os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so"), lib)
@@ -20,7 +22,7 @@ for co in sorted(glob.glob(lib + ".*gfx950")):
     text += subprocess.run([OBJDUMP, "-d", co], stdout=subprocess.PIPE, text=True).stdout
 lines = text.split("\n")
 name = "_Z19swg_diag_dyn_kernelILi%dELi" % K     # <K, waves the instantiation was compiled for, no edges, not wide>
-start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <%s\d+ELb0ELb0E" % name, l))
+start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <%s\d+ELb%dELb%dE" % (name, EDGES, WIDE), l))
 end = start + 1
 while end < len(lines) and not re.match(r"^[0-9a-f]+ <_Z", lines[end]):
     end += 1
@@ -66,7 +68,8 @@ for l in body[a:b]:
     mix[k] += 1
     if not k.startswith("VALU recurrence"):
         others.append("    %-22s %s" % (p[0], p[1][:80]))
-print("kernel %s..., %d instructions in all; one unrolled row = %d static instructions" % (name, len(body), b - a))
+print("kernel %s...%s%s, %d instructions in all; one unrolled row = %d static instructions"
+      % (name, " EDGES" * EDGES, " WIDE" * WIDE, len(body), b - a))
 print("(both lane-group hand-over forms -- row_shr for 16/32 lanes, wave_shr for 64 -- and the skipped")
 print(" score-store / queue-event blocks are in the listing: a row executes only one form)")
 for k, v in sorted(mix.items(), key=lambda kv: -kv[1]):
