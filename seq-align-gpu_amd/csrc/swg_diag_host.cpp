@@ -303,7 +303,7 @@ static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint32_t *t)
     const uint8_t *cx = db->codes.data() + db->code_off[2 * p];
     const uint8_t *cy = has_y ? db->codes.data() + db->code_off[2 * p + 1] : nullptr;
     t[0] = kTokReset; // reset rows: padding residue for both sequences
-    t[1] = kTokReset;
+    t[1] = kTokReset | SWG_TOK_RESET2;
     uint32_t *r = t + 2;
     const uint32_t both = std::min(lx, ly); // (= ly: sorted order)
     for (uint32_t j = 0; j < both; ++j) r[j] = (uint32_t)cx[j] | (uint32_t)cy[j] << 8;

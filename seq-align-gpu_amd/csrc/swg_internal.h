@@ -55,6 +55,7 @@ struct SwgDiagParams {
 // its second, then flags.
 #define SWG_TOK_RESET 0x10000u
 #define SWG_TOK_LAST 0x20000u
+#define SWG_TOK_RESET2 0x80000u // with RESET: the second of a pair's two reset rows (the wide cells wipe their state on the first only)
 #define SWG_TOK_IDLE 0x40000u // first row after a lane group's last pair (several passes only): the tail lane stops storing edges
 
 // The same fill with pairs handed out by device-wide counters.

@@ -1053,7 +1053,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 uint32_t fm = 0u - ((tok >> 16) & 1u);
                 asm volatile("" : "+v"(fm)); // (keeps this a branch: flattened into selects it costs six instructions on every row)
                 if (WIDE) {
-                    cells.wipe(fm);
+                    // (a wiped lane fed zero edges stays wiped: the first of the two reset rows is enough, and
+                    // rows that are special for another flag skip the 3K+2 selects)
+                    const uint32_t fw = fm & (((tok >> 19) & 1u) - 1u);
+                    if (__builtin_amdgcn_ballot_w64(fw != 0u) != 0ull) cells.wipe(fw);
                 } else {
                     cells.best &= ~fm;
                     go_v |= fm;
@@ -1500,7 +1503,7 @@ __global__ void swg_build_tokens_kernel(const uint32_t *codes, const uint64_t *c
     for (int r = 0; r < 4; ++r) t[r] = ((xw >> (8 * r)) & 0xFFu) | (((yw >> (8 * r)) & 0xFFu) << 8);
     if (k == 0u) {
         t[0] |= SWG_TOK_RESET;
-        t[1] |= SWG_TOK_RESET;
+        t[1] |= SWG_TOK_RESET | SWG_TOK_RESET2;
     }
     const uint32_t last = lx + 1u; // row of X's last residue
     if (last / 4u == k) t[last & 3u] |= SWG_TOK_LAST;

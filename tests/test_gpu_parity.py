@@ -708,7 +708,10 @@ def test_device_built_tokens_equal_the_host_builder(swg, ctx, n, n_empty, max_le
     assert np.array_equal(dev, host), int(np.nonzero(dev != host)[0][0])
     # every pair carries exactly one last-row flag: the tail lane pops one pair id per flag
     assert int(((dev & 0x20000) != 0).sum()) == (db.count + 1) // 2
-    assert ((dev & 0xFFFC0707) == 0).all()                 # residue bytes are index << 3, flags are bits 16 and 17
+    assert ((dev & 0xFFF40707) == 0).all()                 # residue bytes are index << 3, flags are bits 16, 17 and 19
+    # two reset rows open every pair; the second one says so (bit 19)
+    assert int(((dev & 0x10000) != 0).sum()) == 2 * ((db.count + 1) // 2)
+    assert np.array_equal((dev & 0x80000) != 0, np.roll((dev & 0x90000) == 0x10000, 1))
     db.close()
 
 

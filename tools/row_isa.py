@@ -57,7 +57,10 @@ def kind(op):
 # rows are unrolled four times; a row's profile addresses are formed by two SDWA adds (residue bytes 0
 # and 1 of the token): a row is taken from one BYTE_0 add to the next
 starts = [i for i, l in enumerate(body) if ("v_add_u32_sdwa" in l or "v_xor_b32_sdwa" in l) and "BYTE_0" in l]
-a, b = starts[1], starts[2]
+# the kernel holds its main loop twice (16-lane groups: row_shr hand-over; wider groups: wave_shr): take a
+# row of the 16-lane loop, the one the headline shapes run
+rows16 = [(x, y) for x, y in zip(starts, starts[1:]) if any("row_shr:1" in l for l in body[x:y]) and y - x < 700]
+a, b = rows16[1]
 mix = collections.Counter()
 others = []
 for l in body[a:b]:
@@ -70,8 +73,7 @@ for l in body[a:b]:
         others.append("    %-22s %s" % (p[0], p[1][:80]))
 print("kernel %s...%s%s, %d instructions in all; one unrolled row = %d static instructions"
       % (name, " EDGES" * EDGES, " WIDE" * WIDE, len(body), b - a))
-print("(both lane-group hand-over forms -- row_shr for 16/32 lanes, wave_shr for 64 -- and the skipped")
-print(" score-store / queue-event blocks are in the listing: a row executes only one form)")
+print("(a row of the loop for 16-lane groups; the skipped score-store / flag blocks are in the listing)")
 for k, v in sorted(mix.items(), key=lambda kv: -kv[1]):
     print("  %4d  %s" % (v, k))
 print("everything that is not the recurrence, in program order:")
