@@ -1455,8 +1455,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
 
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[0], s));
-    HIP_TRY(ctx, hipMemsetAsync(db->d_scores, 0, n_slots * 4, s));
-    HIP_TRY(ctx, hipMemsetAsync(db->d_counters, 0, SWG_COUNTER_BYTES, s));
+    HIP_TRY(ctx, swg_launch_zero2(db->d_scores, n_slots * 4, db->d_counters, SWG_COUNTER_BYTES, s)); // (one launch, not two memsets)
 
     SwgFillParams p;
     memset(&p, 0, sizeof p);

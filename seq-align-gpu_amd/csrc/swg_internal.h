@@ -190,6 +190,7 @@ hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code
                                  uint32_t *d_packed, hipStream_t stream);
 
 // Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, or 65535 in the wide form) to list.
+hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t stream);
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling,
                                         uint32_t *d_list, uint32_t *d_count,
                                         hipStream_t stream);

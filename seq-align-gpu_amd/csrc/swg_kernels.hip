@@ -2064,6 +2064,26 @@ hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, 
     return hipGetLastError();
 }
 
+// zeroes two regions (sizes in 16-byte units) in ONE launch: a search's score array and its counters, which as
+// two hipMemsetAsync were two runtime fill kernels plus the gaps between them ahead of every fill
+__global__ void swg_zero2_kernel(uint4 *a, uint32_t na, uint4 *b, uint32_t nb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    if (i < na) a[i] = z;
+    else if (i - na < nb) b[i - na] = z;
+}
+
+hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t stream)
+{
+    if ((a_bytes | b_bytes) & 15u || ((a_bytes + b_bytes) >> 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    const uint32_t na = (uint32_t)(a_bytes >> 4), nb = (uint32_t)(b_bytes >> 4);
+    if (na + nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_zero2_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, stream, static_cast<uint4 *>(a), na,
+                       static_cast<uint4 *>(b), nb);
+    return hipGetLastError();
+}
+
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling, uint32_t *d_list,
                                         uint32_t *d_count, hipStream_t stream)
 {

@@ -46,7 +46,7 @@ def main(budget=300.0, seed=1):
         flat = np.concatenate(seqs); off = np.zeros(len(lens) + 1, dtype=np.uint64); off[1:] = np.cumsum(lens)
         want = orc.score_db(q, flat, off, sc.table(), go, ge)
         ctx.set_scoring(sc, go, ge); ctx.set_query(q)
-        for k in ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups"):
+        for k in ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups", "segment_blocks"):
             ctx.set_option(k, 0)
         for k in ("work_queue", "wide16", "autotune", "side_readout"):
             ctx.set_option(k, 1)
@@ -66,6 +66,8 @@ def main(budget=300.0, seed=1):
         if rng.random() < 0.2: opts["long_helps"] = 1
         if rng.random() < 0.2: opts["autotune"] = 0
         if rng.random() < 0.15: opts["wide16"] = 0
+        if rng.random() < 0.25:   # multi-pass launches cut into segments of consecutive pairs (never shorter than a pair)
+            opts["segment_blocks"] = int((max(lens) + 5) // 4 * rng.choice([1, 2, 7]) + rng.integers(0, 3))
         if "cols_per_wave" in opts and opts["cols_per_wave"] * opts["group_lanes"] * 64 > 150 * 1024:
             opts = {}
         for k, v in opts.items(): ctx.set_option(k, v)
