@@ -285,7 +285,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
         # a query of several passes is one launch of the fill kernel per pass: the roofline figures are per
         # launch (what rocprofv3's per-kernel average and the PMC counters are), so the step's fill time
         # and its algorithmic bytes are divided by the number of launches
-        launches = max(1, int(last["passes"])) if last["engine"] == 2 and last["path_bits"] == 16 and last["work_queue"] else 1
+        launches = max(1, int(last["fill_launches"])) if last["engine"] == 2 and last["path_bits"] == 16 and last["work_queue"] else 1
         step_fill_ms = float(np.mean(fill_ms))
         k_ms = step_fill_ms / launches
         bytes_alg = int(last["bytes_alg"]) // launches

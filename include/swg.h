@@ -89,7 +89,9 @@ typedef struct swg_stats {
      * sharing a hardware queue -- a host program with many HIP streams should raise GPU_MAX_HW_QUEUES --
      * or its workgroups found no room); -1 = a single class, nothing to overlap. */
     int32_t classes_overlapped;
-    int32_t reserved_;
+    /* launches of the main fill kernel in this search: one per pass of the query, times the segments a
+     * pass of a very large database is cut into; 1 for a query of one pass */
+    int32_t fill_launches;
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */

@@ -75,7 +75,7 @@ class Stats(C.Structure):
         ("workgroups", C.c_int32), ("engine", C.c_int32), ("group_lanes", C.c_int32),
         ("streams", C.c_int32), ("long_pairs", C.c_int32), ("long_cols_per_lane", C.c_int32),
         ("long_streams", C.c_int32), ("work_queue", C.c_int32), ("classes_overlapped", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("fill_launches", C.c_int32),
     ]
 
     def as_dict(self):

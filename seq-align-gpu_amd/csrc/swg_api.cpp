@@ -789,6 +789,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                     HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pl.wide != 0, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
                 }
             }
+            if (c == 0) ctx->cur->fill_launches = pl.npass * (int)segs.size();
             continue;
         }
         SwgDiagParams d;
@@ -1467,6 +1468,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     p.scratch = ctx->d_scratch;
 
     bool two_ends = false;
+    ctx->cur->fill_launches = 0;
     if (!use_diag && !use_q32) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
     if (use_diag) {
         if ((rc = launch_diag(ctx, db, wk, go, ge, &two_ends)) != SWG_OK) return rc;
@@ -1655,6 +1657,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         st.group_lanes = dpl.G;
         st.waves = dpl.W;
         st.passes = dpl.npass;
+        st.fill_launches = S->fill_launches > 0 ? S->fill_launches : dpl.npass;
         st.workgroups = diag_class_workgroups(ctx, db, wk, 0);
         st.work_queue = diag_class_is_dynamic(ctx, db, dpl) ? 1 : 0;
         st.streams = (int32_t)diag_class_streams(ctx, db, wk, 0);
@@ -1700,6 +1703,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         st.workgroups = S->main_wgs;
         st.cells_padded = (uint64_t)S->main_npass * S->main_W * S->main_K * db->rows_padded;
     }
+    if (st.fill_launches <= 0) st.fill_launches = std::max(1, st.passes);
 
     const auto t0 = std::chrono::steady_clock::now();
     if (scores_out) {
@@ -2042,6 +2046,7 @@ extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *qu
     st.group_lanes = wk.plan[0].G;
     st.waves = wk.plan[0].W;
     st.passes = 1;
+    st.fill_launches = 1;
     if (wk.n_classes == 2) {
         st.long_pairs = (int32_t)(wk.pair_end[1] - wk.pair_begin[1]);
         st.long_cols_per_lane = wk.plan[1].K;

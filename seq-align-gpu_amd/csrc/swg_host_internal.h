@@ -160,6 +160,7 @@ struct SwgSlot {
     bool use_diag = false, use_diag32 = false, use_q32 = false;
     SwgDiagWork wk32; // int32 work-queue fill of the whole database
     int bits = 0, npass32 = 0, main_K = 0, main_W = 0, main_npass = 0, main_wgs = 0;
+    int fill_launches = 0; // launches of the bulk class's fill kernel (passes x segments)
     SwgDiagWork wk;
     swg_stats st;
     uint64_t *h_cand = nullptr;     // pinned, SWG_TOPK_CAND_CAP keys

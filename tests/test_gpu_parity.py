@@ -369,6 +369,22 @@ def test_errors_are_codes_not_crashes(swg, ctx):
     empty = swg.Database(np.zeros(0, np.int8), np.zeros(1, np.uint64)).upload(ctx)
     scores, hits, st = ctx.search(empty, k=5)
     assert scores.size == 0 and hits == [] and st["cells"] == 0
+    # a segment of the multi-pass fill shorter than one pair of sequences cannot be launched: an error, not a hang
+    g3 = load_golden("blosum62_lq3000")
+    _setup(ctx, g3)
+    db3 = swg.Database(g3["flat"], g3["offsets"]).upload(ctx)
+    ctx.set_option("engine", 2)
+    ctx.set_option("segment_blocks", 8)
+    with pytest.raises(swg.SwgError) as e:
+        ctx.search(db3)
+    assert e.value.code == swg.SWG_ERR_ARG
+    with pytest.raises(swg.SwgError):
+        ctx.set_option("segment_blocks", 1 << 27)
+    ctx.set_option("segment_blocks", 0)
+    scores, _, _ = ctx.search(db3)
+    assert np.array_equal(scores, g3["oracle32"])
+    db3.close()
+    _reset_options(ctx)
 
 
 def test_full_size_config2_properties(swg, ctx, orc):
@@ -586,6 +602,9 @@ def test_multipass_through_the_work_queue(swg, ctx, orc):
         scores, _, st = ctx.search(db)
         assert np.array_equal(scores, g["oracle32"]), (opts, st)
         assert st["work_queue"] == 1 and st["passes"] > 1
+        # one launch per pass, times the segments when the database is cut into them
+        assert (st["fill_launches"] > st["passes"]) if "segment_blocks" in opts else (st["fill_launches"] == st["passes"]), st
+        assert st["fill_launches"] % st["passes"] == 0
         ctx.set_option("work_queue", 0)
         scores0, _, st0 = ctx.search(db)
         assert np.array_equal(scores0, g["oracle32"]) and st0["work_queue"] == 0 and st0["passes"] == st["passes"]
