@@ -2066,43 +2066,61 @@ extern "C" int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size
     if (!ctx || (!batches && n_batches))
         return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_fill_batches16: NULL argument");
     if (fill_seconds) *fill_seconds = 0.0;
+    // diagnostics: SWG_TIMING=1 prints where the wall time of this call went
+    static const bool timing = getenv("SWG_TIMING") != nullptr;
+    typedef std::chrono::steady_clock clk;
+    clk::time_point tp[8];
+    tp[0] = clk::now();
     std::vector<uint64_t> offsets(1, 0);
-    size_t total = 0;
-    for (size_t b = 0; b < n_batches; ++b) {
-        if (!batches[b].db_idx_t || !batches[b].max_scores || batches[b].vector_size > 16 ||
-            batches[b].max_len == 0)
-            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_fill_batches16: bad batch %zu", b);
-        total += batches[b].max_len * batches[b].vector_size;
-    }
-    std::vector<int8_t> flat(total);
-    size_t pos = 0;
-    for (size_t b = 0; b < n_batches; ++b) {
-        const swg_batch16 &bt = batches[b];
-        for (size_t l = 0; l < bt.vector_size; ++l) {
+    std::vector<size_t> first_rec(n_batches);
+    try {
+        for (size_t b = 0; b < n_batches; ++b) {
+            if (!batches[b].db_idx_t || !batches[b].max_scores || batches[b].vector_size > 16 ||
+                batches[b].max_len == 0)
+                return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_fill_batches16: bad batch %zu", b);
+            first_rec[b] = offsets.size() - 1;
             // lane l, padded rows included: the reference computes them as real
             // rows (src/alignment_cmdline.c:448-450)
-            for (size_t j = 0; j < bt.max_len; ++j) flat[pos++] = bt.db_idx_t[j * 16 + l];
-            offsets.push_back(pos);
+            for (size_t l = 0; l < batches[b].vector_size; ++l) offsets.push_back(offsets.back() + batches[b].max_len);
         }
+    } catch (const std::exception &) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
     }
+    std::unique_ptr<int8_t[]> flat(new (std::nothrow) int8_t[std::max<uint64_t>(1, offsets.back())]);
+    if (!flat) return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
+    swg_untranspose_batches16(batches, n_batches, first_rec.data(), offsets.data(), flat.get());
+    tp[1] = clk::now();
     const size_t n = offsets.size() - 1;
     if (n == 0) return SWG_OK;
     swg_db *db = nullptr;
-    int rc = swg_db_pack(flat.data(), offsets.data(), n, 0, 1, &db);
+    int rc = swg_db_pack(flat.get(), offsets.data(), n, 0, 1, &db);
     if (rc != SWG_OK) {
         ctx->err = swg_global_error();
         return rc;
     }
+    tp[2] = clk::now();
     rc = swg_db_upload(ctx, db);
+    tp[3] = clk::now();
     std::vector<int32_t> scores(n, 0);
     swg_stats st;
+    // (this database is searched exactly once: the cost model's geometry, no timed trials)
+    const auto keep_autotune = ctx->opt_autotune;
+    ctx->opt_autotune = 0;
     if (rc == SWG_OK) rc = swg_search(ctx, db, scores.data(), nullptr, 0, nullptr, &st);
+    ctx->opt_autotune = keep_autotune;
+    tp[4] = clk::now();
     swg_db_free(db);
+    tp[5] = clk::now();
     if (rc != SWG_OK) return rc;
     size_t i = 0;
     for (size_t b = 0; b < n_batches; ++b)
         for (size_t l = 0; l < batches[b].vector_size; ++l, ++i)
             batches[b].max_scores[l] = (int16_t)std::min<int32_t>(scores[i], 32767);
     if (fill_seconds) *fill_seconds = st.total_ms * 1e-3;
+    if (timing) {
+        auto ms = [&](int i) { return std::chrono::duration<double, std::milli>(tp[i + 1] - tp[i]).count(); };
+        fprintf(stderr, "[swg_fill_batches16] %zu records: un-transpose %.2f ms, pack %.2f, upload %.2f, search %.2f (device %.2f), free %.2f\n",
+                n, ms(0), ms(1), ms(2), ms(3), st.total_ms, ms(4));
+    }
     return SWG_OK;
 }

@@ -233,6 +233,8 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
                           std::vector<uint32_t> *pair_off);
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
                            uint32_t streams_per_wg, SwgDiagLayout *out);
+void swg_untranspose_batches16(const swg_batch16 *batches, size_t n_batches, const size_t *first_rec,
+                               const uint64_t *rec_off, int8_t *flat);
 uint64_t swg_db_pair_count(const swg_db *db);
 // rows (2 reset rows + longer length) of the pairs [pair_begin, pair_end): total and longest
 uint64_t swg_db_pair_rows(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint64_t *longest_rows);

@@ -194,6 +194,29 @@ template <class V> bool get(FILE *f, V &v, size_t n)
 }
 } // namespace
 
+// Reference-shaped batches (alignment_fill_matrices' input: db_idx_t[max_len][16], the 16 lanes of a row
+// side by side, src/alignment_cmdline.c:434,445) back into records laid end to end, padded rows included
+// (the reference computes them as real rows).  first_rec[b] = index of batch b's lane 0 among the records,
+// rec_off = the records' offsets in flat.  All cores: this is most of what the compatibility route costs.
+void swg_untranspose_batches16(const swg_batch16 *batches, size_t n_batches, const size_t *first_rec,
+                               const uint64_t *rec_off, int8_t *flat)
+{
+#pragma omp parallel for schedule(dynamic, 16) num_threads(swg_host_threads())
+    for (long long b = 0; b < (long long)n_batches; ++b) {
+        const swg_batch16 &bt = batches[b];
+        const int8_t *src = bt.db_idx_t;
+        int8_t *dst[16];
+        for (size_t l = 0; l < bt.vector_size; ++l) dst[l] = flat + rec_off[first_rec[b] + l];
+        if (bt.vector_size == 16) {
+            for (size_t j = 0; j < bt.max_len; ++j, src += 16)
+                for (int l = 0; l < 16; ++l) dst[l][j] = src[l];
+        } else {
+            for (size_t j = 0; j < bt.max_len; ++j, src += 16)
+                for (size_t l = 0; l < bt.vector_size; ++l) dst[l][j] = src[l];
+        }
+    }
+}
+
 extern "C" int swg_db_save(const swg_db *db, const char *path)
 {
     if (!db || !path) return swg_set_global_error(SWG_ERR_ARG, "swg_db_save: NULL argument");
