@@ -169,6 +169,7 @@ _sig("swg_synth_db_shard", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_dou
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)])
 _sig("swg_synth_free", None, [_vp])
 # test hook, declared in csrc/swg_host_internal.h (not part of the public ABI)
+_sig("swg_debug_plan", C.c_int, [_vp, C.c_size_t, C.c_int, _vp])
 _sig("swg_debug_pair_tokens", C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)])
 
 
@@ -368,6 +369,13 @@ class Database:
         if self.count == 0:                 # a shard may hold nothing (fewer bins than shards)
             return np.zeros(0, dtype=np.uint32)
         return np.ctypeslib.as_array(lib.swg_db_order(self.handle), shape=(self.count,)).copy()
+
+    def debug_plan(self, lq, n_cu=256):
+        """Test hook: the cost model's first choice for this database and a query of lq residues (no device needed)."""
+        out = np.zeros(12, dtype=np.int32)
+        _check(lib.swg_debug_plan(self.handle, lq, n_cu, out.ctypes.data_as(_vp)))
+        keys = ("classes", "K", "G", "W", "passes", "workgroups", "long_pairs", "long_K", "long_G", "long_W", "long_workgroups", "est_us")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def debug_pair_tokens(self, ctx, from_host):
         """Test hook: the pair-token image (uint32 dwords) built on the device or by the host builder."""

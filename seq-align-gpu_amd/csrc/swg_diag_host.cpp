@@ -413,3 +413,24 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
         write_pair_tokens(db, (size_t)p, base + (size_t)(*pair_off)[p] * 4);
     return 0;
 }
+
+// Test hook (not part of the public ABI, declared in swg_host_internal.h): the cost model's first choice
+// for a packed database and a query length on a device of n_cu compute units, without a device.
+// out[0..11] = classes, K, G, W, passes, workgroups, long pairs, long K, long G, long W, long workgroups,
+// estimated microseconds.
+extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *out)
+{
+    if (!db || !out || lq == 0 || n_cu <= 0) return SWG_ERR_ARG;
+    SwgDiagWork wk;
+    try {
+        if (swg_plan_diag_work(db, lq, n_cu, 0, 0, 0, 0, true, true, &wk) <= 0) return SWG_ERR_ARG;
+    } catch (const std::exception &) {
+        return SWG_ERR_NOMEM;
+    }
+    const SwgDiagPlan &b = wk.plan[0], &l = wk.plan[1];
+    const bool two = wk.n_classes == 2;
+    const int32_t v[12] = {wk.n_classes, b.K, b.G, b.W, b.npass, b.workgroups, two ? (int32_t)(wk.pair_end[1] - wk.pair_begin[1]) : 0,
+                           two ? l.K : 0, two ? l.G : 0, two ? l.W : 0, two ? l.workgroups : 0, (int32_t)(b.est_ms * 1e3)};
+    memcpy(out, v, sizeof v);
+    return SWG_OK;
+}

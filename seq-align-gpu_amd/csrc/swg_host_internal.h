@@ -214,6 +214,7 @@ int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
     __attribute__((format(printf, 3, 4)));
 void swg_db_release_device(swg_db *db);
 // test hook: the pair-token image as the device built it, or as the host restatement builds it
+extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *out);
 extern "C" int swg_debug_pair_tokens(swg_ctx *ctx, swg_db *db, int from_host, uint32_t *out, size_t cap_dwords,
                                      size_t *n_dwords);
 
