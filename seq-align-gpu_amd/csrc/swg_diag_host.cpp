@@ -151,12 +151,15 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                 // CUs between them (timed faster in isolation, slower back to back).  Larger ones only
                 // where LDS allows a single workgroup per CU and more wavefronts mean more occupancy.
                 if (dynamic && opt_waves == 0 && wps != 1) {
+                    // (occupancy by the workgroup's real LDS size, lane-group records included: at exactly two
+                    // profiles per CU they decide whether a second workgroup fits)
+                    auto occupancy = [&](int w) {
+                        const size_t l = swg_diag_dyn_lds_bytes(info.K, G, 4 * w);
+                        return std::min(4, w * std::max(1, std::min<int>(info.max_waves / (4 * w), (int)((160 * 1024) / l))));
+                    };
                     bool improves = true;
-                    for (int w2 = 1; w2 < wps; ++w2) {
-                        const int pc2 = std::max(1, std::min<int>(info.max_waves / (4 * w2), (int)((160 * 1024) / lds)));
-                        if (std::min(4, w2 * pc2) >= std::min(4, wps * std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)))))
-                            improves = false;
-                    }
+                    for (int w2 = 1; w2 < wps; ++w2)
+                        if (occupancy(w2) >= occupancy(wps)) improves = false;
                     if (!improves) continue;
                 }
                 // (the work-queue kernels keep a 512-byte record per lane group behind the profile)

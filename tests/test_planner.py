@@ -50,7 +50,7 @@ def test_config5_long_query_near_copies(swg):
 
 
 @pytest.mark.parametrize("lq,want", [(600, (1, 19, 32, 4, 1)), (800, (1, 25, 32, 12, 1)), (1000, (1, 32, 32, 12, 1)),
-                                     (1500, (1, 24, 64, 12, 1)), (2000, (1, 32, 64, 12, 1))])
+                                     (1200, (1, 19, 64, 12, 1)), (1500, (1, 24, 64, 12, 1)), (2000, (1, 32, 64, 12, 1))])
 def test_single_pass_lengths_between_the_configs(swg, lq, want):
     """What the autotuner picked on the device when the model was last compared with it:
     no long class for a tie, 12 wavefronts per workgroup where LDS keeps four from the same occupancy."""
