@@ -239,11 +239,11 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     // rates, a thinning tail): measured 4 900 against 5 600 GCUPS on config 2
                     if (!dynamic) cycles *= 1.15;
                     // Workgroups of more than four wavefronts are candidates only where they raise the
-                    // occupancy (above).  In a single pass they then deliver it (round 2, 200 000 sequences:
-                    // lq 800 7 030 against 6 750 GCUPS, lq 1000 7 060 against 6 820 with 12 wavefronts);
-                    // in a launch per pass the longest pair's chain is what a third wavefront per SIMD
-                    // slows down (config 5: 6 070 with 12 against 6 590 with 8).
-                    if (dynamic && W > 4 && npass > 1) cycles *= 1.08;
+                    // occupancy (above), and then they deliver it -- round 2, 200 000 sequences: lq 800 7 030
+                    // against 6 750 GCUPS, lq 1000 7 060 against 6 820, lq 2500 (3 passes) 6 800 against 6 450
+                    // with 12 wavefronts instead of 4 -- so they carry no penalty of their own (round 1 had one).
+                    // Where a third wavefront per SIMD hurts, it is through the longest pair's chain, which
+                    // `crit` prices (config 5's 8 200-row near-copies: 6 070 with 12 against 6 590 with 8).
                     // a second class is a second launch that takes LDS and issue slots from the bulk: worth
                     // it where the chain decides, not for a tie (lq 600: 6 420 with 19 long pairs, 6 880 without)
                     if (split) cycles *= 1.02;

@@ -58,6 +58,14 @@ def test_single_pass_lengths_between_the_configs(swg, lq, want):
     assert (p["classes"], p["K"], p["G"], p["W"], p["passes"]) == want, p
 
 
+@pytest.mark.parametrize("lq,want", [(2500, (1, 27, 32, 12, 3)), (4000, (1, 32, 64, 12, 2)), (6000, (1, 32, 64, 12, 3))])
+def test_several_passes_with_wide_groups(swg, lq, want):
+    """Few passes of wide groups (12 wavefronts per workgroup) beat many of narrow ones when no pair is long
+    against a pass: the autotuner's picks on the device, 3 to 4 % above what the model chose before."""
+    p = _plan(swg, 0x5EED0003, 200000, lq)
+    assert (p["classes"], p["K"], p["G"], p["W"], p["passes"]) == want, p
+
+
 def test_tiny_database_takes_the_widest_groups(swg):
     p = _plan(swg, 0x5EED0001, 1024, 128)
     assert p["G"] == 64 and p["passes"] == 1 and p["K"] * 64 >= 128, p
