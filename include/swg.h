@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SWG_ABI_VERSION 2
+#define SWG_ABI_VERSION 3
 
 typedef enum swg_status {
     SWG_OK = 0,
@@ -92,6 +92,10 @@ typedef struct swg_stats {
     /* launches of the main fill kernel in this search: one per pass of the query, times the segments a
      * pass of a very large database is cut into; 1 for a query of one pass */
     int32_t fill_launches;
+    /* the cells the 16-bit fill ran on: 0 packed int16 (scores to 32767), 1 the wide int16 form (to 65535),
+     * 2 packed f16 with gfx950's three-operand maxima (exact below 2048; a sequence that reaches it is
+     * flagged and re-scored in int32 like an int16 saturation) */
+    int32_t cell_form;
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */

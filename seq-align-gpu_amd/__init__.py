@@ -76,6 +76,7 @@ class Stats(C.Structure):
         ("streams", C.c_int32), ("long_pairs", C.c_int32), ("long_cols_per_lane", C.c_int32),
         ("long_streams", C.c_int32), ("work_queue", C.c_int32), ("classes_overlapped", C.c_int32),
         ("fill_launches", C.c_int32),
+        ("cell_form", C.c_int32),
     ]
 
     def as_dict(self):

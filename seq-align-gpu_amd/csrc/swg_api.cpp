@@ -190,6 +190,9 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         ctx->opt_side_readout = value != 0;
     } else if (!strcmp(key, "wide16")) {
         ctx->opt_wide = value != 0;
+    } else if (!strcmp(key, "f16")) {
+        if (value < 0 || value > 2) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "f16 must be 0 (off), 1 (auto) or 2 (whenever the gap scores allow)");
+        ctx->opt_f16 = value;
     } else if (!strcmp(key, "long_helps")) {
         ctx->opt_long_helps = value != 0;
     } else if (!strcmp(key, "segment_blocks")) {
@@ -455,11 +458,12 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
 }
 
 static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom, int k_real = 1,
-                               int k_padded = 1, int chunk_cols = 4, int swizzle_lanes = 0)
+                               int k_padded = 1, int chunk_cols = 4, int swizzle_lanes = 0, int f16 = 0)
 {
     const size_t bytes = (size_t)ncols * 32 * elem_size;
     // (query, scoring) epoch and geometry: the epoch is spread over all 64 bits so that no geometry field can alias it
-    const uint64_t tag = (ctx->epoch * 0x9E3779B97F4A7C15ull) ^ geom ^ ((uint64_t)swizzle_lanes << 56) ^ ((uint64_t)chunk_cols << 60);
+    const uint64_t tag = (ctx->epoch * 0x9E3779B97F4A7C15ull) ^ geom ^ ((uint64_t)swizzle_lanes << 56) ^ ((uint64_t)chunk_cols << 60) ^
+                         ((uint64_t)(f16 != 0) << 53);
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
     if (bytes > ctx->d_profile_cap[which]) {
         (void)hipFree(ctx->d_profile[which]);
@@ -470,7 +474,7 @@ static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem
     }
     HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols,
                                           elem_size, chunk_cols, k_real, k_padded, ctx->d_profile[which], ctx->stream,
-                                          swizzle_lanes));
+                                          swizzle_lanes, f16));
     ctx->profile_tag[which] = tag;
     return SWG_OK;
 }
@@ -603,6 +607,27 @@ static bool diag_class_is_dynamic(const swg_ctx *ctx, const swg_db *db, const Sw
     return pl.npass == 1 || db->ptok.total_blocks < (1ull << 30);
 }
 
+// The cells a class runs on (CellsDiag FORM): packed f16 and the wide form exist in the work-queue kernels
+// (the wide form also in the fixed-stream one).
+static int diag_class_form(const swg_ctx *ctx, const swg_db *db, const SwgDiagPlan &pl)
+{
+    if (pl.f16 && diag_class_is_dynamic(ctx, db, pl)) return 2;
+    return pl.wide ? 1 : 0;
+}
+
+// An integer 0..2048 as an f16 bit pattern (exact), in both halves of a dword.
+static uint32_t f16x2_of(int v)
+{
+    uint32_t b = 0;
+    if (v > 0) {
+        int e = 0;
+        while ((v >> (e + 1)) != 0) ++e; // floor(log2 v), <= 11
+        const uint32_t mant = (e <= 10 ? (uint32_t)v << (10 - e) : (uint32_t)v >> (e - 10)) & 0x3FFu;
+        b = ((uint32_t)(e + 15) << 10) | mant;
+    }
+    return b | (b << 16);
+}
+
 // Workgroups to launch for class c.  Work-queue kernels are persistent: a workgroup that is not
 // resident from the start only gets in when another one has run out of pairs, so when the long
 // class runs beside the bulk the bulk leaves it its wave slots (one per SIMD per long workgroup).
@@ -676,7 +701,7 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
         const uint32_t ncols = (uint32_t)(pl.npass * pl.G * kp);
         int rc = ensure_profile_cols(ctx, diag_profile_slot(pl, c), ncols, 2,
                                      (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols, pl.K, kp, 4,
-                                     SWG_LDS_SWIZZLE ? pl.G : 0);
+                                     SWG_LDS_SWIZZLE ? pl.G : 0, diag_class_form(ctx, db, pl) == 2);
         if (rc != SWG_OK) return rc;
     }
     return SWG_OK;
@@ -722,8 +747,9 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.scores = db->d_scores;
             q.pair_limit = (uint32_t)(((size_t)db->n_bins * SWG_BIN) / 2);
             q.G = (uint32_t)pl.G;
-            q.go = g | (g << 16);
-            q.ge = e | (e << 16);
+            const int form = diag_class_form(ctx, db, pl);
+            q.go = form == 2 ? f16x2_of(-go) : g | (g << 16);
+            q.ge = form == 2 ? f16x2_of(-ge) : e | (e << 16);
             // the long class always runs at raised priority; in the bulk, a pair that alone is well
             // above an average lane group's whole share
             auto bulk_prio = [&]() -> uint32_t {
@@ -745,7 +771,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             q.trace = d_trace[c];
             // start / end wall-clock stamps of single-pass launches: words 8..15 of the counters
             q.stamps = pl.npass == 1 ? reinterpret_cast<unsigned long long *>(db->d_counters + 8 + 4 * c) : nullptr;
-            const bool edges = pl.npass > 1 || pl.wide != 0;
+            const bool edges = pl.npass > 1 || form == 1;
             const size_t slice = (size_t)pl.G * swg_diag_padded_cols(pl.K) * 64;
             hipStream_t qs = c == 1 ? ctx->stream2 : s;
             // The form with edges addresses a launch's tokens and edges by 32-bit offsets: pairs whose
@@ -786,7 +812,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                         q.seg_origin = T.pair_blocks_prefix[sg.first];
                         q.seg_blocks = T.pair_blocks_prefix[sg.second] - q.seg_origin;
                     }
-                    HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pl.wide != 0, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
+                    HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, form, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
                 }
             }
             if (c == 0) ctx->cur->fill_launches = pl.npass * (int)segs.size();
@@ -1109,12 +1135,14 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
 
 // First search of a query length on a database: the cost model ranks the geometries, the few
 // best are timed once on this device (each is a complete, valid fill) and the fastest is kept.
-static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, SwgTuned *tuned)
+static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, SwgTuned *tuned, int form)
 {
     SwgDiagWork *best = &tuned->wk;
     std::vector<SwgDiagWork> cands;
     const bool work_queue = ctx->opt_dynamic != 0 && db->ptok.ok;
-    if (swg_plan_diag_candidates(db, lq, ctx->n_cu, 0, 0, 0, 0, true, work_queue, &cands) <= 0) return SWG_ERR_ARG;
+    if (swg_plan_diag_candidates(db, lq, ctx->n_cu, 0, 0, 0, 0, true, work_queue, &cands, 1.0, form) <= 0) return SWG_ERR_ARG;
+    for (SwgDiagWork &c : cands) // (the trials run on the cells the search will use)
+        for (int k = 0; k < c.n_classes; ++k) c.plan[k].f16 = form == 2;
     // distinct (K, G, W, split) among the best-ranked
     std::vector<SwgDiagWork> pick;
     for (const SwgDiagWork &c : cands) {
@@ -1180,8 +1208,10 @@ static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, Sw
             const long thr = (long)std::max(64.0, (dyn ? fr_dyn[i] : fr_static[i]) * unit);
             std::vector<SwgDiagWork> alt;
             if (swg_plan_diag_candidates(db, lq, ctx->n_cu, base.plan[0].K, base.plan[0].G, base.plan[0].W, thr, true,
-                                         work_queue, &alt) <= 0)
+                                         work_queue, &alt, 1.0, form) <= 0)
                 continue;
+            for (SwgDiagWork &c : alt)
+                for (int k = 0; k < c.n_classes; ++k) c.plan[k].f16 = form == 2;
             const SwgDiagWork *same = nullptr;
             for (const SwgDiagWork &c : alt)
                 if (c.n_classes == 2 && c.plan[1].K == base.plan[1].K && c.plan[1].G == base.plan[1].G) {
@@ -1327,6 +1357,15 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     const uint64_t longest = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK;
     const uint64_t score_bound = std::min<uint64_t>(qbound, std::min<uint64_t>(lq, longest) * (uint64_t)smax);
     bool wide = bits == 16 && score_bound >= 32767ull && ctx->opt_engine != 1 && ctx->opt_wide != 0;
+    // The packed-f16 cells (three-operand maxima, 8.5 instead of 10 instructions per column pair) are exact
+    // while scores stay below 2048; a sequence that reaches it is flagged and re-scored in int32.  They are the
+    // first step whenever the gap magnitudes are f16 integers and the query is not so long that scores are
+    // expected far beyond (where the wide form is exact on its own) -- unless this database has shown, for this
+    // query, that a good part of its rows gets flagged ("f16" option: 0 never, 2 regardless of both).
+    const bool want_f16 = bits == 16 && ctx->opt_engine != 1 && ctx->opt_dynamic != 0 && ctx->opt_f16 != 0 && -go <= 2048 &&
+                          -ge <= 2048 && (ctx->opt_f16 == 2 || (score_bound < 32767ull && db->f16_veto_epoch != ctx->epoch));
+    if (want_f16) wide = false; // (only with f16 = 2: the f16 cells first, whatever the score bound)
+    const int plan_form = want_f16 ? 2 : 0;
 
     Plan main_pl, re_pl;
     memset(&main_pl, 0, sizeof main_pl);
@@ -1343,12 +1382,13 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         const bool free_geometry = ctx->opt_cols == 0 && ctx->opt_group == 0 && ctx->opt_max_waves == 0 &&
                                    ctx->opt_long_split == 0 && ctx->opt_workgroups == 0;
         swg_db *mdb = const_cast<swg_db *>(db);
-        auto it = free_geometry ? mdb->tuned.find(lq) : mdb->tuned.end();
+        const uint64_t tuned_key = (uint64_t)lq | ((uint64_t)plan_form << 40); // (a geometry is tuned for the cells it ran on)
+        auto it = free_geometry ? mdb->tuned.find(tuned_key) : mdb->tuned.end();
         if (it == mdb->tuned.end() && free_geometry && ctx->opt_autotune && ctx->opt_engine == 0 &&
             db->n_local >= 4096 && db->n_local <= (4u << 20)) {
             SwgTuned tn;
-            if (autotune_diag(ctx, mdb, lq, go, ge, &tn) == SWG_OK && tn.wk.n_classes > 0)
-                it = mdb->tuned.insert(std::make_pair((uint64_t)lq, tn)).first;
+            if (autotune_diag(ctx, mdb, lq, go, ge, &tn, plan_form) == SWG_OK && tn.wk.n_classes > 0)
+                it = mdb->tuned.insert(std::make_pair(tuned_key, tn)).first;
         }
         if (it != mdb->tuned.end() && !(wide && it->second.engine == 1)) {
             if (it->second.engine == 1 && ctx->opt_engine == 0) {
@@ -1367,7 +1407,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         if (!use_diag && !tuned_systolic)
             use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
                                           ctx->opt_long_split, ctx->opt_workgroups == 0,
-                                          ctx->opt_dynamic != 0 && db->ptok.ok, &wk) > 0;
+                                          ctx->opt_dynamic != 0 && db->ptok.ok, &wk, 1.0, plan_form) > 0;
         if (!use_diag && !tuned_systolic && ctx->opt_engine == 2)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
         if (use_diag && ctx->opt_workgroups > 0) {
@@ -1383,8 +1423,31 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         else
             wide = false;
     }
+    // int32 work (forced / unusual gap scores / re-score of saturated sequences) also runs on
+    // the diagonal engine unless the systolic one is asked for
+    const bool use_diag32 = ctx->opt_engine != 1;
+    // Non-positive gap scores: the int32 work-queue kernel (8 instructions per cell, any lane-group
+    // geometry, sequences off the queue) instead of the bin-based one (12 per cell, 64 lanes x 16 columns
+    // whatever the query length).
+    bool q32_ok = fast_ok && use_diag32 && ctx->opt_dynamic != 0;
+    {
+        SwgDiagWork probe; // (one pass up to about 1150 columns, else several)
+        q32_ok = q32_ok && q32_list_plan(ctx, lq, 1, &probe);
+    }
+    // the f16 cells: every class on the work queue, and a re-score path for what they flag
+    bool use_f16 = want_f16 && use_diag;
+    for (int c = 0; use_f16 && c < wk.n_classes; ++c) use_f16 = diag_class_is_dynamic(ctx, db, wk.plan[c]);
+    if (q32_ok && (bits == 32 || score_bound >= (use_f16 ? 2048ull : wide ? 65535ull : 32767ull))) {
+        if ((rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
+        SwgDiagWork probe;
+        q32_ok = db->ptok.ok && q32_list_plan(ctx, lq, 1, &probe) &&
+                 (probe.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28)); // (32-bit edge indices)
+    }
+    if (use_f16 && score_bound >= 2048ull && !q32_ok) use_f16 = false;
+    for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].f16 = use_f16 ? 1 : 0;
+    const int32_t ceiling = use_f16 ? 2048 : wide ? 65535 : 32767;
     const SwgDiagPlan &dpl = wk.plan[0];
-    const bool may_saturate = bits == 16 && score_bound >= (wide ? 65535ull : 32767ull);
+    const bool may_saturate = bits == 16 && score_bound >= (uint64_t)ceiling;
     if (may_saturate) {
         const long keep_cols = ctx->opt_cols;
         ctx->opt_cols = 0; // the int32 re-score uses its default geometry
@@ -1392,24 +1455,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         ctx->opt_cols = keep_cols;
         if (rc != SWG_OK) return rc;
     }
-    // int32 work (forced / unusual gap scores / re-score of saturated sequences) also runs on
-    // the diagonal engine unless the systolic one is asked for
-    const bool use_diag32 = ctx->opt_engine != 1;
     const int npass32 = (int)((lq + 64 * SWG_DIAG32_K - 1) / (64 * SWG_DIAG32_K));
-    // Non-positive gap scores and a query of one pass: the int32 work-queue kernel (8 instructions per
-    // cell, any lane-group geometry, pairs off the queue) instead of the bin-based one (12 per cell,
-    // 64 lanes x 16 columns whatever the query length).
-    bool q32_ok = fast_ok && use_diag32 && ctx->opt_dynamic != 0;
-    {
-        SwgDiagWork probe; // (one pass up to about 1150 columns, else several)
-        q32_ok = q32_ok && q32_list_plan(ctx, lq, 1, &probe);
-    }
-    if (q32_ok && (bits == 32 || may_saturate)) {
-        if ((rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
-        SwgDiagWork probe;
-        q32_ok = db->ptok.ok && q32_list_plan(ctx, lq, 1, &probe) &&
-                 (probe.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28)); // (32-bit edge indices)
-    }
     SwgDiagWork wk32;
     bool use_q32 = false;
     if (bits == 32 && q32_ok) {
@@ -1424,7 +1470,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             }
         }
     }
-    if (use_diag32 && (bits == 32 || may_saturate) && !use_q32) {
+    const bool bin32 = use_diag32 && ((bits == 32 && !use_q32) || (may_saturate && !q32_ok)); // the bin-based int32 kernel is needed
+    if (bin32) {
         rc = ensure_profile_cols(ctx, 1, (uint32_t)(npass32 * 64 * SWG_DIAG32_K), 4, (1ull << 30) ^ (uint64_t)npass32);
         if (rc != SWG_OK) return rc;
         const size_t per_wave = ((size_t)db->max_nblk * 4 + 4) * 4; // dwords: one uint4 per stream row
@@ -1441,8 +1488,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     if (may_saturate && !use_diag32 && (rc = ensure_profile(ctx, re_pl)) != SWG_OK) return rc;
     {
         size_t need = 0;
-        if (use_diag32 && (bits == 32 || may_saturate) && npass32 > 1)
-            need = ((size_t)db->max_nblk * 4 + 4) * 4 * 16 * (size_t)ctx->n_cu;
+        if (bin32 && npass32 > 1) need = ((size_t)db->max_nblk * 4 + 4) * 4 * 16 * (size_t)ctx->n_cu;
         if (!use_diag && !(bits == 32 && use_diag32) && main_pl.npass > 1)
             need = std::max(need, (size_t)main_pl.workgroups * db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb);
         if (may_saturate && !use_diag32 && re_pl.npass > 1)
@@ -1506,8 +1552,9 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
     if (!use_diag && !use_q32) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
     if (may_saturate) {
-        HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, wide ? 65535 : 32767, db->d_list,
-                                                  db->d_counters + 1, s));
+        // counters [1] = flagged sequences, [6] = their rows in units of 16 (what the f16 veto looks at)
+        HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, ceiling, db->d_list, db->d_counters + 1, db->d_lens,
+                                                  db->d_counters + 6, s));
         p.profile = ctx->d_profile[1];
         p.queue = db->d_counters + 2;
         p.list = db->d_list;
@@ -1515,23 +1562,29 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         p.n_items = 0;
         p.go = go;
         p.ge = ge;
-        if (use_diag32) {
-            // how many were flagged decides the shape of the re-score (4 bytes over PCIe):
-            // usually none, then nothing is launched; a few long ones get a whole CU each
+        SwgDiagWork wkl;
+        // The work-queue re-score reads the count on the device and leaves at once when it is zero, so it is queued
+        // behind every fill that may flag something and the host never waits for the count in the middle of a
+        // search (it did until round 3: a round trip per search, and the end of the two-deep pipeline of
+        // swg_search_begin).  Only its lane-group width is a guess -- few flagged sequences get 64 lanes each,
+        // many the narrowest group that covers the query -- made from what the last search of this database saw.
+        const uint32_t guess = db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
+        if (use_diag32 && q32_ok && q32_list_plan(ctx, lq, guess, &wkl)) {
+            // (fresh queue counters and rank table: the fill's are spent; no events of its own: the
+            // re-score is timed as ev[2] .. ev[3] like the other re-score forms)
+            HIP_TRY(ctx, hipMemsetAsync(db->d_counters + SWG_QUEUE_WORD(0), 0,
+                                        (size_t)(SWG_COUNTER_BYTES - SWG_QUEUE_WORD(0) * 4u), s));
+            bool two = false;
+            rc = launch_q32(ctx, db, wkl, go, ge, db->d_list, db->d_counters + 1, std::max<uint32_t>(2u * guess, 4096u),
+                            db->d_counters + SWG_QUEUE_WORD(0), &two, false);
+            if (rc != SWG_OK) return rc;
+        } else if (use_diag32) {
+            // the bin-based kernel (positive gap scores never get here; a database beyond the queue's
+            // indices, work_queue = 0): its shape comes from the count, read back over PCIe
             uint32_t n_sat = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&n_sat, db->d_counters + 1, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, spin_sync(ctx, s));
-            SwgDiagWork wkl;
-            if (n_sat > 0 && q32_ok && q32_list_plan(ctx, lq, n_sat, &wkl)) {
-                // (fresh queue counters and rank table: the fill's are spent; no events of its own: the
-                // re-score is timed as ev[2] .. ev[3] like the other re-score forms)
-                HIP_TRY(ctx, hipMemsetAsync(db->d_counters + SWG_QUEUE_WORD(0), 0,
-                                            (size_t)(SWG_COUNTER_BYTES - SWG_QUEUE_WORD(0) * 4u), s));
-                bool two = false;
-                rc = launch_q32(ctx, db, wkl, go, ge, db->d_list, db->d_counters + 1, n_sat, db->d_counters + SWG_QUEUE_WORD(0), &two,
-                                false);
-                if (rc != SWG_OK) return rc;
-            } else if (n_sat > 0) {
+            if (n_sat > 0) {
                 int W = (int)((n_sat + (uint32_t)ctx->n_cu - 1) / (uint32_t)ctx->n_cu);
                 W = std::min(16, std::max(4, (W + 3) / 4 * 4));
                 const int wgs = (int)std::min<uint32_t>((uint32_t)ctx->n_cu, (n_sat + W - 1) / W);
@@ -1571,6 +1624,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     S->use_diag = use_diag;
     S->use_diag32 = use_diag32;
     S->use_q32 = use_q32;
+    S->used_f16 = use_f16;
+    S->epoch = ctx->epoch;
     S->wk32 = wk32;
     S->npass32 = npass32;
     S->wk = wk;
@@ -1641,6 +1696,14 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     const double topk_dev_ms = ms;
     st.n_rescored = h_counters[1];
     st.path_bits = bits;
+    st.cell_form = use_diag ? diag_class_form(ctx, db, dpl) : 0;
+    if (may_saturate) {
+        // what the next search's plan may assume (never its results)
+        swg_db *mdb = const_cast<swg_db *>(db);
+        mdb->sat_hint = (long long)h_counters[1];
+        // f16 cells that flag more than 1/50 of the rows cost more in re-scores than they save
+        if (S->used_f16 && (uint64_t)h_counters[6] * 16ull * 50ull > db->residues + 2ull * db->n_local) mdb->f16_veto_epoch = S->epoch;
+    }
     st.classes_overlapped = -1;
     if (use_diag && wk.n_classes == 2 && wk.plan[0].npass == 1 && wk.plan[1].npass == 1) {
         // did the two classes run side by side?  (stamps: complement of the earliest start, latest end)
@@ -2018,7 +2081,7 @@ extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *qu
             }
             q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
             q.simd_ranks = B.d_cnt + Qb_max * 2 * cnt_class + (size_t)c * SWG_DYN_SIMD_SLOTS;
-            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, false, false, pl.W, wgs[c], q, c == 1 ? ctx->stream2 : s, (int)Qb));
+            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, false, 0, pl.W, wgs[c], q, c == 1 ? ctx->stream2 : s, (int)Qb));
         }
         if (wk.n_classes == 2) {
             HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[7], ctx->stream2));

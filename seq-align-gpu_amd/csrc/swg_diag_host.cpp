@@ -53,7 +53,8 @@ uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)
 //   dominate small databases.
 // 10 per column pair plus the row's bookkeeping: 14 instructions, but worth about 30 issue slots
 // (DPP wait states, the wait for the row's first profile read) by the K = 16 / 24 / 32 comparison
-static double instr_per_row(int K, int G) { return 10.0 * K + (G == 32 ? 34.0 : 30.0); }
+// (the packed-f16 cells, form 2, take 8.5 per column pair: DESIGN 4.1)
+static double instr_per_row(int K, int G, int form = 0) { return (form == 2 ? 8.5 : 10.0) * K + (G == 32 ? 34.0 : 30.0); }
 // one pass of several through the work queue: row index, edge hand-over to the leader, the tail's
 // edge store
 static const double kEdgeInstr = 7.0;
@@ -63,7 +64,7 @@ static const double kEdgeInstr = 7.0;
 long g_swg_long_cols = 0;  // experiment switch: restrict the long class to this K (0 = free)
 long g_swg_long_group = 0; // experiment switch: restrict the long class to this G (0 = free)
 
-static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_cycles, bool dynamic, SwgDiagPlan *lp)
+static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_cycles, bool dynamic, SwgDiagPlan *lp, int form)
 {
     bool ok = false, ok_fit = false;
     double best_cost = 1e300, best_depth = 1e300;
@@ -84,7 +85,7 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
             if ((size_t)G * swg_diag_padded_cols(info.K) * 64 > 160 * 1024) continue;
             const int npass = (int)((lq + cols - 1) / cols);
             if (dynamic && npass > 1) continue; // the queue serves single-pass classes only
-            const double instr = npass * instr_per_row(info.K, G);
+            const double instr = npass * instr_per_row(info.K, G, form);
             const double cost = instr / (64 / G);                     // per pair-row
             const double depth = ((double)longest_rows + G) * instr * kHotCycles;
             SwgDiagPlan c;
@@ -112,7 +113,7 @@ static bool long_class_geometry(size_t lq, uint64_t longest_rows, double budget_
 
 int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
                              long opt_long_split, bool allow_split, bool work_queue, std::vector<SwgDiagWork> *cands,
-                             double copies)
+                             double copies, int form)
 {
     // copies > 1: the same database is searched by that many queries in ONE launch (swg_search_multi):
     // all throughput terms grow with it, the longest chain of rows does not
@@ -141,7 +142,7 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
             // chain that matters is the longest pair at the rate of a wavefront that gets its fair
             // share of the SIMD
             const bool dynamic = work_queue && (npass == 1 || db->n_local < (1u << 30));
-            const double instr = instr_per_row(info.K, G) + (dynamic && npass > 1 ? kEdgeInstr : 0.0);
+            const double instr = instr_per_row(info.K, G, form) + (dynamic && npass > 1 ? kEdgeInstr : 0.0);
             for (int wps = 1; wps <= 4; ++wps) {
                 const int W = 4 * wps;
                 if (W > info.max_waves) continue;
@@ -216,7 +217,7 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                             lp.npass = npass;
                             lp.W = 4;
                             lp.lds_bytes = lds;
-                        } else if (!long_class_geometry(lq, longest_long, 0.8 * bulk_cycles, dynamic, &lp)) {
+                        } else if (!long_class_geometry(lq, longest_long, 0.8 * bulk_cycles, dynamic, &lp, form)) {
                             continue;
                         }
                         const uint64_t lspw = 4ull * (64 / lp.G);
@@ -224,7 +225,7 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                         lstreams = std::max<uint64_t>(1, std::min<uint64_t>(dynamic ? (uint64_t)((double)n_long * copies) : (n_long + 1) / 2,
                                                                             (uint64_t)n_cu * lspw));
                         lstreams = (lstreams + lspw - 1) / lspw * lspw;
-                        const double linstr = instr_per_row(lp.K, lp.G);
+                        const double linstr = instr_per_row(lp.K, lp.G, form);
                         work += rows_long / (64 / lp.G) * lp.npass * linstr * cps;
                         const double lcrit = (std::max<double>(rows_long / lstreams, (double)longest_long) + lp.G) *
                                              lp.npass * linstr * kHotCycles;
@@ -286,12 +287,12 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
 }
 
 int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk, double copies)
+                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk, double copies, int form)
 {
     std::vector<SwgDiagWork> c;
     wk->n_classes = 0;
     if (swg_plan_diag_candidates(db, lq, n_cu, opt_cols, opt_group, opt_waves, opt_long_split, allow_split, work_queue,
-                                 &c, copies) > 0)
+                                 &c, copies, form) > 0)
         *wk = c[0];
     return wk->n_classes;
 }

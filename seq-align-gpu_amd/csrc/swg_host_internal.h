@@ -74,6 +74,7 @@ struct SwgPairTokens {
 struct SwgDiagPlan {
     int variant = 0, K = 0, G = 0, npass = 0, W = 0, workgroups = 0;
     int wide = 0; // scores to 65535 (values biased by -32768)
+    int f16 = 0;  // packed-f16 cells with three-operand maxima: scores below 2048, anything above flagged and re-scored
     uint32_t n_streams = 0;
     size_t lds_bytes = 0;
     double est_ms = 0.0;
@@ -117,6 +118,13 @@ struct swg_db {
     SwgPairTokens ptok;             // pair-major tokens (work-queue form of the diagonal engine)
     SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs
     std::map<uint64_t, SwgTuned> tuned; // query length -> engine + geometry that measured fastest on this device
+    // What the last finished search of this database saw (plans of later searches only: results never depend
+    // on it).  sat_hint: sequences its 16-bit fill flagged for the re-score (-1: no search yet), by which
+    // the re-score's lane-group width is picked without reading the count back in the middle of a search;
+    // f16_veto_epoch: the (query, scoring) epoch for which the packed-f16 cells flagged so many rows (a
+    // database full of close relatives of the query) that the int16 cells are the faster first step.
+    long long sat_hint = -1;
+    uint64_t f16_veto_epoch = 0;
     // device image (valid after swg_db_upload): the residue bytes and three words per slot; the pair
     // tokens (ptok) and the bin image are built FROM them on the device, the bins only when an
     // engine that reads them is used (swg_ensure_bins)
@@ -158,6 +166,8 @@ struct SwgSlot {
     size_t k = 0, first_chunk = 0;
     bool want_scores = false, dev_topk = false, need_scores = false, two_ends = false, may_saturate = false;
     bool use_diag = false, use_diag32 = false, use_q32 = false;
+    bool used_f16 = false;  // the fill ran on the packed-f16 cells
+    uint64_t epoch = 0;     // the context's (query, scoring) epoch the search was queued under
     SwgDiagWork wk32; // int32 work-queue fill of the whole database
     int bits = 0, npass32 = 0, main_K = 0, main_W = 0, main_npass = 0, main_wgs = 0;
     int fill_launches = 0; // launches of the bulk class's fill kernel (passes x segments)
@@ -189,7 +199,7 @@ struct swg_ctx {
     hipEvent_t ev_query_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     int query_stage_next = 0;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 0, opt_wide = 1, opt_side_readout = 1;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 0, opt_wide = 1, opt_side_readout = 1, opt_f16 = 1;
     uint32_t opt_seg_blocks = SWG_DYN_SEG_BLOCKS; // token blocks per launch of the multi-pass fill (option "segment_blocks": tests)
     // device state
     int8_t *d_sub = nullptr;
@@ -222,11 +232,12 @@ extern "C" int swg_debug_pair_tokens(swg_ctx *ctx, swg_db *db, int from_host, ui
 // geometry of both classes for one query length on one device; returns the number of
 // classes (0: the diagonal engine cannot run this with the given options)
 int swg_plan_diag_work(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
-                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk, double copies = 1.0);
+                       long opt_long_split, bool allow_split, bool work_queue, SwgDiagWork *wk, double copies = 1.0,
+                       int form = 0); // form: the cells the plan is for (2: packed f16, 8.5 instead of 10 instructions per column pair)
 // every geometry the model considered, best estimate first (the autotuner times the first few)
 int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_cols, long opt_group, long opt_waves,
                              long opt_long_split, bool allow_split, bool work_queue,
-                             std::vector<SwgDiagWork> *cands, double copies = 1.0);
+                             std::vector<SwgDiagWork> *cands, double copies = 1.0, int form = 0);
 // 0 on success; -1 when the database is too large for 32-bit block offsets.  tok == NULL: only
 // pair_off (the tokens themselves are built on the device, swg_launch_build_tokens); otherwise also
 // the host builder's token image, which the tests compare the device's with.

@@ -152,7 +152,8 @@ SwgKernelInfo swg_diag_variant_info(int variant); // K, max_waves (wave budget o
 hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int workgroups, size_t lds_bytes,
                            const SwgDiagParams &p, hipStream_t stream);
 size_t swg_diag_dyn_lds_bytes(int K, int G, int W);
-hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int workgroups, const SwgDiagDynParams &p,
+// form: the cells (CellsDiag): 0 packed int16, 1 wide int16 (edges only), 2 packed f16 with three-operand maxima
+hipError_t swg_launch_diag_dyn(int variant, bool edges, int form, int W, int workgroups, const SwgDiagDynParams &p,
                                hipStream_t stream, int n_queries = 1);
 // profiles of n_queries queries (query i = queries[q_off[i] .. q_off[i+1])) in one launch: query i's
 // profile of ncols layout columns goes to d_profiles + i * ncols * 32 * 2 (int16)
@@ -177,7 +178,8 @@ hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_
 // width of the kernel that will read it: a lane's rows are stored at residue ^ (lane-in-group & 31)
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
                                     uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols, int k_real,
-                                    int k_padded, uint8_t *d_profile, hipStream_t stream, int swizzle_lanes = 0);
+                                    int k_padded, uint8_t *d_profile, hipStream_t stream, int swizzle_lanes = 0,
+                                    int f16 = 0); // f16: elem_size 2 entries are f16 numbers (pad -65504) for the packed-f16 cells
 int swg_diag_padded_cols(int K); // layout columns of a lane's slice
 
 // Per-database layouts from the uploaded residue dwords (d_code_off in dwords): the pair-major
@@ -189,10 +191,12 @@ hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code
                                  const uint64_t *d_bin_off, const uint32_t *d_bin_nblk, uint32_t n_bins,
                                  uint32_t *d_packed, hipStream_t stream);
 
-// Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, or 65535 in the wide form) to list.
+// Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, 65535 in the wide form, 2048 for the
+// packed-f16 cells) to list.
 hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t stream);
+// d_lens / d_rows16 (or NULL): also adds up the flagged sequences' lengths, in units of 16 rows.
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling,
-                                        uint32_t *d_list, uint32_t *d_count,
+                                        uint32_t *d_list, uint32_t *d_count, const uint32_t *d_lens, uint32_t *d_rows16,
                                         hipStream_t stream);
 
 // Device top-K (see swg_kernels.hip): after the call d_thr[1] == 0 means d_cand[0..min(*d_count,cap))

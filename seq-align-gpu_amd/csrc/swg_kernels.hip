@@ -78,6 +78,23 @@ DEVINL uint32_t pk_max_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a),
                                                                   __builtin_bit_cast(s16x2, b)));
 }
+// packed f16 (the three-operand-maximum cells, CellsDiag FORM 2): values are integers, exact up to 2048
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+DEVINL uint32_t pk_add_f16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b));
+}
+DEVINL uint32_t pk_sub_f16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) - __builtin_bit_cast(f16x2, b));
+}
+// v_pk_maximum3_f16 (gfx950): the compiler forms it from two nested IEEE-754-2019 maxima
+DEVINL uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a),
+                                                                                                    __builtin_bit_cast(f16x2, b)),
+                                                                      __builtin_bit_cast(f16x2, c)));
+}
 // LDS access by 32-bit LDS address: the lane-group kernels form their profile addresses with one SDWA
 // instruction from a per-lane base that already holds the array's LDS address (no add of the array
 // symbol per read).
@@ -453,15 +470,29 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 #define DPP_ROW_SHR1 0x111
 #define DPP_WAVE_SHR1 0x138
 
-// WIDE: the same recurrence on values biased by -32768 (a score v is held as v - 32768), which
-// doubles the range to 65535 at the same instruction count: the signed saturating subtract floors
-// at -32768 = score 0, the signed saturating add sticks at 32767 = score 65535, signed max keeps
-// the order.  Used when the query is long enough for a score to pass 32767 (the reference's int16
-// lanes wrap there).  Reset rows cannot use the all-ones gap trick in this form and
-// wipe the state explicitly.
-template <int K, bool WIDE = false> struct CellsDiag {
+// The cells come in three forms of the same recurrence (FORM):
+//  0  packed int16, unsigned saturating subtracts do the floors: scores to 32767 (a score that reaches it sticks
+//     there and the sequence is flagged), 10 VALU instructions per 2 cells.
+//  1  "wide": the same on values biased by -32768 (a score v is held as v - 32768), which doubles the range to
+//     65535 at the same instruction count: the signed saturating subtract floors at -32768 = score 0, the signed
+//     saturating add sticks at 32767 = score 65535, signed max keeps the order.  Used when the query is long
+//     enough for a score to pass 32767 (the reference's int16 lanes wrap there).  Reset rows cannot
+//     use the all-ones gap trick in this form and wipe the state explicitly.
+//  2  packed f16 with gfx950's three-operand maximum (v_pk_maximum3_f16): the floors are the third operand of
+//     the maxima that are needed anyway, M = max3(t, a, b) is one instruction instead of two and the running
+//     best takes two columns per instruction: 8.5 instructions per 2 cells.  Every value is an integer; f16
+//     holds integers exactly up to 2048, and sums of two such values round monotonically, so a pair whose
+//     computed best stays below 2048 has had every cell computed exactly; a pair that reaches 2048
+//     is flagged and re-scored.  G is kept unfloored (M - |go| may be negative; the max3 floors it where it is
+//     used).  Reset rows: gap magnitudes of 65504, the largest finite f16, clear every finite state in two rows;
+//     a lane whose best reached +inf (a score beyond 65504 in the making) is wiped explicitly.  The profile holds
+//     f16 bit patterns, -65504 for padding; no NaN can arise (no -inf exists, +inf meets only finite values).
+#define SWG_F16_BIG 0x7BFF7BFFu  // 65504 in both halves
+#define SWG_F16_FLAG 0x6800u     // 2048.0: a score that reaches it is flagged
+template <int K, int FORM = 0> struct CellsDiag {
+    static constexpr bool WIDE = FORM == 1, F16 = FORM == 2;
     static constexpr uint32_t ZERO = WIDE ? 0x80008000u : 0u;
-    DEVINL static uint32_t sub(uint32_t a, uint32_t b) { return WIDE ? pk_sub_i16_sat(a, b) : pk_sub_u16_sat(a, b); }
+    DEVINL static uint32_t sub(uint32_t a, uint32_t b) { return F16 ? pk_sub_f16(a, b) : WIDE ? pk_sub_i16_sat(a, b) : pk_sub_u16_sat(a, b); }
     // A profile chunk is [32 residues][4 columns] int16 = 256 bytes; a lane's slice of the profile
     // is KP = K rounded up to whole chunks, the columns it works on are the first K (any K: G*K
     // lands within G/2 columns of the query length on average instead of 2*G).
@@ -479,7 +510,7 @@ template <int K, bool WIDE = false> struct CellsDiag {
         mdl = ZERO;
     }
 
-    // lanes with fm = all ones forget everything (WIDE form of a reset row)
+    // lanes with fm = all ones forget everything (WIDE form of a reset row; F16: a lane that reached +inf)
     DEVINL void wipe(uint32_t fm)
     {
 #pragma unroll
@@ -490,6 +521,12 @@ template <int K, bool WIDE = false> struct CellsDiag {
         }
         best = (best & ~fm) | (ZERO & fm);
         mdl = (mdl & ~fm) | (ZERO & fm);
+    }
+
+    // F16: all ones in lanes whose running best holds +inf in either half
+    DEVINL uint32_t best_is_inf() const
+    {
+        return 0u - (uint32_t)((((best & 0x7C007C00u) + 0x04000400u) & 0x80008000u) != 0u);
     }
 
     // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows).  ax / ay: 32-bit LDS
@@ -517,20 +554,37 @@ template <int K, bool WIDE = false> struct CellsDiag {
             s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
             s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
             s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
+            uint32_t mprev = 0u;
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int k = CH * c + u;
                 if (k >= K) break; // unused tail of the last chunk
-                const uint32_t t = pk_add_i16_sat(md, s[u]);
-                md = M[k];
-                const uint32_t a = pk_max_i16(G[k], sub(A[k], ge));
-                const uint32_t b = pk_max_i16(gl, sub(bl, ge));
-                const uint32_t m = pk_max_i16(pk_max_i16(t, a), b);
-                M[k] = m;
-                A[k] = a;
-                gl = G[k] = sub(m, go);
-                bl = b;
-                best = pk_max_i16(best, m);
+                if (F16) {
+                    const uint32_t t = pk_add_f16(md, s[u]);
+                    md = M[k];
+                    const uint32_t a = pk_max3_f16(G[k], pk_sub_f16(A[k], ge), 0u);
+                    const uint32_t b = pk_max3_f16(gl, pk_sub_f16(bl, ge), 0u);
+                    const uint32_t m = pk_max3_f16(t, a, b);
+                    M[k] = m;
+                    A[k] = a;
+                    gl = G[k] = pk_sub_f16(m, go);
+                    bl = b;
+                    // the running best takes two columns at a time (the last one of an odd K alone)
+                    if (u & 1) best = pk_max3_f16(best, mprev, m);
+                    else if (k == K - 1) best = pk_max3_f16(best, m, m);
+                    mprev = m;
+                } else {
+                    const uint32_t t = pk_add_i16_sat(md, s[u]);
+                    md = M[k];
+                    const uint32_t a = pk_max_i16(G[k], sub(A[k], ge));
+                    const uint32_t b = pk_max_i16(gl, sub(bl, ge));
+                    const uint32_t m = pk_max_i16(pk_max_i16(t, a), b);
+                    M[k] = m;
+                    A[k] = a;
+                    gl = G[k] = sub(m, go);
+                    bl = b;
+                    best = pk_max_i16(best, m);
+                }
             }
             if (FENCED && c + 1 < NCH) __builtin_amdgcn_sched_barrier(0);
         }
@@ -538,6 +592,13 @@ template <int K, bool WIDE = false> struct CellsDiag {
         return make_uint2(M[K - 1], bl);
     }
 };
+
+// integer score of a packed-f16 best (one half, as it comes out of the LDS maximum): flagged at 2048
+DEVINL int f16_score(uint32_t bits)
+{
+    if (bits >= SWG_F16_FLAG) return 2048;
+    return (int)(float)__builtin_bit_cast(_Float16, (unsigned short)bits);
+}
 
 template <int CTRL> DEVINL uint32_t dpp_zero(uint32_t src)
 {
@@ -811,10 +872,12 @@ DEVINL uint32_t quad_bcast(uint32_t x, int r)
 // when a pair's first reset row reaches it (always at unrolled row 3: the tail is G-1 = 3 mod 4 rows
 // behind the leader) from the pair ring, and parks it when the row flagged IDLE -- sent once by a
 // leader that finds the queue empty -- reaches it.
-// WIDE: scores to 65535 (see CellsDiag); needs EDGES (a query that can pass 32767 is long).
-template <int K, int MAXW, bool EDGES = false, bool WIDE = false>
+// FORM: the cells (see CellsDiag): 0 packed int16, 1 wide (scores to 65535; needs EDGES: a query that can pass
+// 32767 is long), 2 packed f16 with three-operand maxima (scores below 2048, anything above is flagged).
+template <int K, int MAXW, bool EDGES = false, int FORM = 0>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDynParams p)
 {
+    constexpr bool WIDE = FORM == 1, F16 = FORM == 2;
     static_assert(EDGES || !WIDE, "the wide form is instantiated with edges only");
     extern __shared__ __attribute__((aligned(256))) uint8_t smem[]; // query profile, then the group records
     const int lane = threadIdx.x & 63;
@@ -824,7 +887,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     const int gshift = G == 16 ? 4 : G == 32 ? 5 : 6;
     const int g = lane & (G - 1);
     const bool leader = g == 0, tail = g == G - 1;
-    constexpr uint32_t Z = CellsDiag<K, WIDE>::ZERO; // score 0 in the cells' representation
+    constexpr uint32_t Z = CellsDiag<K, FORM>::ZERO; // score 0 in the cells' representation
     const uint32_t base = prof_base(SWG_LDS_ADDRESS(smem) + (uint32_t)g * (CellsDiag<K>::KP / 4) * CellsDiag<K>::CHUNK, g);
     const uint32_t slice = (uint32_t)G * CellsDiag<K>::KP * 64u;
     // recomputed where it is needed (rarely) instead of living in a register
@@ -847,7 +910,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     }
     __syncthreads();
 
-    CellsDiag<K, WIDE> cells;
+    CellsDiag<K, FORM> cells;
     cells.reset();
     uint32_t tok = 0u, m_out = Z, b_out = Z;
     uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
@@ -1057,6 +1120,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     // rows that are special for another flag skip the 3K+2 selects)
                     const uint32_t fw = fm & (((tok >> 19) & 1u) - 1u);
                     if (__builtin_amdgcn_ballot_w64(fw != 0u) != 0ull) cells.wipe(fw);
+                } else if (F16) {
+                    // (65504 clears every finite state; a lane that reached +inf is wiped by hand)
+                    const uint32_t fi = fm & cells.best_is_inf();
+                    if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) cells.wipe(fi);
+                    cells.best &= ~fm;
+                    go_v = (go_v & ~fm) | (SWG_F16_BIG & fm);
+                    ge_v = (ge_v & ~fm) | (SWG_F16_BIG & fm);
                 } else {
                     cells.best &= ~fm;
                     go_v |= fm;
@@ -1090,8 +1160,12 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, c >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (tail) {
                         const uint32_t pr = st[SWG_DYN_RING + at];
-                        const uint32_t sx = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t sy = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at + 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        uint32_t sx = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        uint32_t sy = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at + 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (F16) { // (non-negative f16 values order like their bit patterns: the LDS maximum was taken on those)
+                            sx = (uint32_t)f16_score(sx);
+                            sy = (uint32_t)f16_score(sy);
+                        }
                         if (pr >= p.pair_limit) {
                             // cannot happen with a well-formed token stream; a stray write must not, either
                         } else if (EDGES) { // one pass of several: the score is the maximum over the passes
@@ -1219,6 +1293,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
         const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         return reinterpret_cast<uint32_t *>(smem + slice) + (((uint32_t)w << (6 - gshift)) + (l >> gshift)) * SWG_DYN_STATE;
     };
+    // (a re-score launch is queued behind every fill that MAY flag something: with an empty list -- the usual
+    // case -- it leaves before it has read a byte of the profile)
+    const uint32_t n_items = p.list_count ? *p.list_count : p.q_end - p.q_begin;
+    if (n_items == 0u) return;
     for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
         *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(p.profile + o);
     {
@@ -1227,7 +1305,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
         for (uint32_t i = (uint32_t)g; i < 2u * SWG_DYN_RING; i += (uint32_t)G) st[SWG_DYN_MAXES + i] = 0u;
     }
     __syncthreads();
-    const uint32_t n_items = p.list_count ? *p.list_count : p.q_end - p.q_begin;
 
     CellsQ32<K> cells;
     cells.reset();
@@ -1419,7 +1496,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
 // ---------------------------------------------------------------------------
 __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
                                          uint32_t ncols, int elem_size, uint32_t ch, uint32_t k_real,
-                                         uint32_t k_padded, uint32_t swizzle_lanes, uint8_t *out)
+                                         uint32_t k_padded, uint32_t swizzle_lanes, int f16, uint8_t *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
     if (t >= ncols * 32u) return;
@@ -1431,7 +1508,9 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
     // row of this residue inside its chunk: the residue itself, or swizzled by the reading lane (SWG_LDS_SWIZZLE)
     const uint32_t row = swizzle_lanes ? code ^ (((col / k_padded) % swizzle_lanes) & 31u) : code;
     const size_t e = (size_t)(col / ch) * (32u * ch) + row * ch + (col % ch); // [col/ch][32][ch]
-    if (elem_size == 2)
+    if (elem_size == 2 && f16) // packed-f16 cells: the score as an f16 number, -65504 for padding
+        reinterpret_cast<_Float16 *>(out)[e] = pad ? (_Float16)-65504.0f : (_Float16)(float)v;
+    else if (elem_size == 2)
         reinterpret_cast<int16_t *>(out)[e] = pad ? (int16_t)-32768 : (int16_t)v;
     else
         reinterpret_cast<int32_t *>(out)[e] = pad ? -(1 << 29) : v;
@@ -1544,10 +1623,13 @@ hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code
 }
 
 __global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, int32_t ceiling, uint32_t *list,
-                                             uint32_t *count)
+                                             uint32_t *count, const uint32_t *lens, uint32_t *rows16)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && scores[i] >= ceiling) list[atomicAdd(count, 1u)] = i;
+    if (i < n && scores[i] >= ceiling) {
+        list[atomicAdd(count, 1u)] = i;
+        if (rows16) atomicAdd(rows16, (lens[i] + 15u) / 16u); // rows the re-score will walk, in units of 16
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1868,7 +1950,7 @@ struct DiagVariant {
     SwgKernelInfo info;
     void (*kernel[2])(const SwgDiagParams); // [0] single pass, [1] multi-pass
     void (*wide)(const SwgDiagParams);      // multi-pass form (also runs one pass), scores to 65535
-    void (*dyn[3])(const SwgDiagDynParams); // pairs off a work queue: single pass; one pass of several; the same, wide form
+    void (*dyn[5])(const SwgDiagDynParams); // pairs off a work queue: single pass; one pass of several; the same, wide form; f16 cells: single pass; one pass of several
 };
 template <int K, int MAXW> DiagVariant make_diag()
 {
@@ -1883,9 +1965,11 @@ template <int K, int MAXW> DiagVariant make_diag()
     v.kernel[0] = swg_diag_kernel<K, MAXW, false>;
     v.kernel[1] = swg_diag_kernel<K, MAXW, true>;
     v.wide = swg_diag_kernel<K, MAXW, true, true>;
-    v.dyn[0] = swg_diag_dyn_kernel<K, MAXW, false, false>;
-    v.dyn[1] = swg_diag_dyn_kernel<K, MAXW, true, false>;
-    v.dyn[2] = swg_diag_dyn_kernel<K, MAXW, true, true>;
+    v.dyn[0] = swg_diag_dyn_kernel<K, MAXW, false, 0>;
+    v.dyn[1] = swg_diag_dyn_kernel<K, MAXW, true, 0>;
+    v.dyn[2] = swg_diag_dyn_kernel<K, MAXW, true, 1>;
+    v.dyn[3] = swg_diag_dyn_kernel<K, MAXW, false, 2>;
+    v.dyn[4] = swg_diag_dyn_kernel<K, MAXW, true, 2>;
     return v;
 }
 const DiagVariant *diag_variants(int *n)
@@ -1993,7 +2077,7 @@ size_t swg_diag_dyn_lds_bytes(int K, int G, int W)
     return (size_t)G * swg_diag_padded_cols(K) * 64u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
 }
 
-hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int workgroups, const SwgDiagDynParams &p,
+hipError_t swg_launch_diag_dyn(int variant, bool edges, int form, int W, int workgroups, const SwgDiagDynParams &p,
                                hipStream_t stream, int n_queries)
 {
     if (n_queries < 1 || n_queries > 65535) return hipErrorInvalidValue;
@@ -2003,7 +2087,8 @@ hipError_t swg_launch_diag_dyn(int variant, bool edges, bool wide, int W, int wo
         (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
         return hipErrorInvalidValue;
     const size_t lds = swg_diag_dyn_lds_bytes(v[variant].info.K, (int)p.G, W);
-    auto k = v[variant].dyn[wide ? 2 : edges ? 1 : 0];
+    if (form < 0 || form > 2 || (form == 1 && !edges)) return hipErrorInvalidValue;
+    auto k = v[variant].dyn[form == 2 ? (edges ? 4 : 3) : form == 1 ? 2 : edges ? 1 : 0];
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -2055,12 +2140,12 @@ hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups, const S
 
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, uint32_t lq,
                                     uint32_t ncols, int elem_size, int chunk_cols, int k_real, int k_padded,
-                                    uint8_t *d_profile, hipStream_t stream, int swizzle_lanes)
+                                    uint8_t *d_profile, hipStream_t stream, int swizzle_lanes, int f16)
 {
     const uint32_t n = ncols * 32u;
     hipLaunchKernelGGL(swg_build_profile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_sub,
                        d_query, lq, ncols, elem_size, (uint32_t)chunk_cols, (uint32_t)k_real, (uint32_t)k_padded,
-                       (uint32_t)swizzle_lanes, d_profile);
+                       (uint32_t)swizzle_lanes, f16, d_profile);
     return hipGetLastError();
 }
 
@@ -2085,10 +2170,10 @@ hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hi
 }
 
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling, uint32_t *d_list,
-                                        uint32_t *d_count, hipStream_t stream)
+                                        uint32_t *d_count, const uint32_t *d_lens, uint32_t *d_rows16, hipStream_t stream)
 {
     if (n_slots == 0) return hipSuccess;
     hipLaunchKernelGGL(swg_collect_saturated_kernel, dim3((n_slots + 255) / 256), dim3(256), 0,
-                       stream, d_scores, n_slots, ceiling, d_list, d_count);
+                       stream, d_scores, n_slots, ceiling, d_list, d_count, d_lens, d_lens ? d_rows16 : nullptr);
     return hipGetLastError();
 }

@@ -126,10 +126,45 @@ def positive_gap_cases():
     emit("blosum62_gap_0_pos1", b62, 0, 1, q, *equal_length_batches(rng, q, [110, 80, 48, 16, 3]))
 
 
+def mutated_prefix(rng, q, length, rate):
+    """The query's first `length` residues with a fraction `rate` of them replaced at random."""
+    s = q[:length].copy()
+    hit = rng.random(length) < rate
+    s[hit] = rand_seq(rng, int(hit.sum()))
+    return s
+
+
+def f16_boundary_cases():
+    """Round 3: databases of close relatives of the query whose scores straddle 2048 -- the ceiling of the packed-f16
+    cells (exact integers up to 2048), above which a sequence is flagged and re-scored in int32.  Batches of 16
+    records, the first the longest, as the reference's packer requires."""
+    rng = np.random.default_rng(20261005)
+    b62, pam = load_matrix("BLOSUM62"), load_matrix("PAM250")
+    for name, sub, go, ge, lq in (("blosum62_f16_boundary", b62, -2, -1, 600), ("blosum62_f16_boundary_gap11", b62, -11, -1, 640),
+                                  ("pam250_f16_boundary", pam, -2, -1, 520)):
+        q = rand_seq(rng, lq)
+        seqs = []
+        for b in range(6):
+            first = lq - 10 * b
+            lens = [first] + sorted((int(rng.integers(lq // 3, first + 1)) for _ in range(15)), reverse=True)
+            for i, L in enumerate(lens):
+                if b == 5 and i % 2:   # unrelated sequences between the relatives
+                    seqs.append(rand_seq(rng, L))
+                else:
+                    seqs.append(mutated_prefix(rng, q, L, float(rng.choice([0.0, 0.03, 0.08, 0.15, 0.25, 0.4]))))
+        flat = np.concatenate(seqs)
+        offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([len(x) for x in seqs])
+        emit(name, sub, go, ge, q, flat, offsets, np.full(6, 16, dtype=np.int32))
+
+
 def main():
     assert orc.have_ref(), "build oracle/_ref first (make -C oracle)"
     if "--positive-gaps" in sys.argv:          # only the fixtures added in round 2 (the others stay byte for byte)
         positive_gap_cases()
+        return
+    if "--f16-boundary" in sys.argv:           # only the fixtures added in round 3
+        f16_boundary_cases()
         return
     rng = np.random.default_rng(20250523)
     pam, b62, b45 = load_matrix("PAM250"), load_matrix("BLOSUM62"), load_matrix("BLOSUM45")
@@ -175,6 +210,7 @@ def main():
     offsets[1:] = np.cumsum(lens)
     emit("pam250_overflow_w", pam, -2, -1, q, flat, offsets, np.array([16], dtype=np.int32), ref_valid=False)
     positive_gap_cases()
+    f16_boundary_cases()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ def _setup(ctx, g):
 
 
 OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups", "segment_blocks")
-DEFAULT_ON = ("work_queue", "wide16")
+DEFAULT_ON = ("work_queue", "wide16", "f16")
 DEFAULT_OFF = ("long_helps",)
 
 
@@ -33,16 +33,28 @@ def _truth(g):
     return g["oracle32"]
 
 
+@pytest.mark.parametrize("cells", ["auto", "int16", "f16"])
 @pytest.mark.parametrize("engine", [1, 2])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_through_search(swg, ctx, name, engine):
+def test_golden_through_search(swg, ctx, name, engine, cells):
+    """cells: which cells the diagonal engine's 16-bit fill runs on -- the library's choice, packed int16 only
+    (option f16 = 0), or the packed-f16 cells whenever the gap scores allow (f16 = 2: exact below 2048, every
+    sequence that reaches it flagged and re-scored in int32; the *_f16_boundary fixtures straddle that ceiling)."""
+    if engine == 1 and cells != "auto":
+        pytest.skip("the systolic engine has int16 cells only")
     g = load_golden(name)
     _setup(ctx, g)
     gaps_ok = g["gaps"][0] <= 0 and g["gaps"][1] <= 0
     ctx.set_option("engine", engine)         # 1 systolic, 2 diagonal (both arithmetic widths)
+    ctx.set_option("f16", {"auto": 1, "int16": 0, "f16": 2}[cells])
     db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
     scores, hits, st = ctx.search(db, k=10)
+    ctx.set_option("f16", 1)
     assert np.array_equal(scores, _truth(g)), (name, st)
+    if cells == "int16" or engine == 1 or not gaps_ok:
+        assert st["cell_form"] in (0, 1)
+    elif cells == "f16":
+        assert st["cell_form"] == 2 and st["n_rescored"] == int((_truth(g) >= 2048).sum()), st
     if g["ref_valid"][0]:
         assert np.array_equal(scores, g["ref16"].astype(np.int32))
     best = sorted(((-int(s), i) for i, s in enumerate(_truth(g))))[:10]
@@ -110,10 +122,12 @@ def test_diagonal_geometry_does_not_change_scores(swg, ctx, cols, group, waves):
     """Columns per lane, lanes per sequence pair, occupancy and the number of query passes
     (1 .. 24 here) are invisible in the result of the diagonal engine."""
     for name in ("blosum62_lq367", "blosum62_lq3000", "pam250_partial_lanes", "blosum62_tiny_db",
-                 "pam250_overflow_w"):
+                 "pam250_overflow_w", "blosum62_f16_boundary", "pam250_f16_boundary"):
         g = load_golden(name)
         _setup(ctx, g)
         ctx.set_option("engine", 2)
+        # (every other geometry also with the f16 cells forced: pam250_overflow_w then runs scores to 51 000 through them)
+        ctx.set_option("f16", 2 if (cols + group // 16) % 2 else 1)
         ctx.set_option("cols_per_wave", cols)
         ctx.set_option("group_lanes", group)
         ctx.set_option("max_waves", waves)
@@ -268,14 +282,18 @@ def test_high_similarity_rescore_matches_oracle(swg, ctx, orc):
     db.close()
 
 
+@pytest.mark.parametrize("f16", [1, 2])
 @pytest.mark.parametrize("geom", [{}, {"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4},
                                   {"cols_per_wave": 24, "group_lanes": 16, "max_waves": 8, "long_split": 900},
                                   {"cols_per_wave": 6, "group_lanes": 64, "max_waves": 4},
                                   {"cols_per_wave": 32, "group_lanes": 32, "max_waves": 4, "long_split": -1}])
-def test_wide16_range_and_beyond(swg, ctx, orc, geom):
+def test_wide16_range_and_beyond(swg, ctx, orc, geom, f16):
     """Scores in every range at once: below 32767, between 32767 and 65535 (wide form, exact) and
     above 65535 (flagged by the wide form, re-scored in int32): a tryptophan-rich query (17 per
-    match in PAM250) against copies of its prefixes, short decoys, and a one-pass geometry."""
+    match in PAM250) against copies of its prefixes, short decoys, and a one-pass geometry.
+    f16 = 2 forces the packed-f16 cells on it: the copies' cells run past 65504 into +inf there, which must
+    neither reach the pairs that follow them in their lane groups nor change any score (everything from 2048
+    up is re-scored in int32)."""
     sc = swg.load_scoring("PAM250")
     rng = np.random.default_rng(33)
     w = swg.synth_query(1, 1)
@@ -293,10 +311,12 @@ def test_wide16_range_and_beyond(swg, ctx, orc, geom):
     _reset_options(ctx)
     for k, v in geom.items():
         ctx.set_option(k, v)
+    ctx.set_option("f16", f16)
     db = swg.Database(flat, off).upload(ctx)
     got, hits, st = ctx.search(db, k=10)
     assert np.array_equal(got, want), (geom, st)
-    assert st["n_rescored"] == int((want >= 65535).sum()) and st["engine"] == 2
+    assert st["cell_form"] == (2 if f16 == 2 else 1)
+    assert st["n_rescored"] == int((want >= (2048 if f16 == 2 else 65535)).sum()) and st["engine"] == 2
     assert hits == orc.topk(want, 10)
     db.close()
     _reset_options(ctx)
@@ -472,7 +492,8 @@ def test_full_size_databases_equal_the_reference_itself(swg, ctx, orc, cfg):
     _reset_options(ctx)
     db = swg.Database(flat, off).upload(ctx)
     scores, _, st = ctx.search(db)
-    assert st["engine"] == 2 and st["path_bits"] == 16 and (st["n_rescored"] == 0 or cfg == "config5")
+    # (f16 cells: exact below 2048, the few sequences that reach it are re-scored)
+    assert st["engine"] == 2 and st["path_bits"] == 16 and (st["n_rescored"] == 0 or cfg == "config5" or st["cell_form"] == 2)
     if cfg == "config5":
         # the same search on the path the configuration is named after: plain int16 (sticks at 32767), every
         # flagged sequence re-scored in int32 -- at full size, all 100 000 scores against the wide form's
@@ -809,7 +830,8 @@ def test_config4_whole_database_on_one_gpu(swg, ctx, orc):
     scores, hits, st = ctx.search(db, k=100)
     ctx.set_option("autotune", 1)
     db.close()
-    assert st["path_bits"] == 16 and st["n_rescored"] == 0 and st["cells"] == lq * int(off[-1])
+    assert st["path_bits"] == 16 and st["cells"] == lq * int(off[-1])
+    assert st["n_rescored"] == (int((scores >= 2048).sum()) if st["cell_form"] == 2 else 0)
     # top-100: consistent with the score vector, and every candidate's score equal to the oracle's
     order = np.lexsort((np.arange(n), -scores.astype(np.int64)))[:100]
     assert hits == [(int(scores[i]), int(i)) for i in order]

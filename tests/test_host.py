@@ -23,7 +23,7 @@ def test_abi_exports_every_declared_symbol(swg):
     for n in names:
         assert hasattr(swg.lib, n), "libswg.so does not export " + n
     assert sorted(names) == sorted(swg.ABI_SYMBOLS)
-    assert swg.lib.swg_abi_version() == 2
+    assert swg.lib.swg_abi_version() == 3
 
 
 def test_no_cpu_fallback(swg):

@@ -1,6 +1,6 @@
 """Static instruction mix of one database row of the work-queue fill kernel, from the built library.
 
-    python tools/row_isa.py [K] [edges] [wide] > profiles/rNN_kK_row_isa.txt
+    python tools/row_isa.py [K] [edges] [wide|f16] > profiles/rNN_kK_row_isa.txt
 
 Extracts the gfx950 code object from seq-align-gpu_amd/libswg.so (llvm-objdump --offloading),
 disassembles swg_diag_dyn_kernel<K,16,false,false> and classifies the instructions of the first
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 23
 EDGES = int("edges" in sys.argv[2:])     # the several-pass variant (edge columns through HBM)
-WIDE = int("wide" in sys.argv[2:])       # the biased variant that counts to 65535
+WIDE = 1 if "wide" in sys.argv[2:] else 2 if "f16" in sys.argv[2:] else 0   # the cells: 0 int16, 1 wide (to 65535), 2 packed f16 with max3
 tmp = tempfile.mkdtemp()
 lib = os.path.join(tmp, "libswg.so")
 shutil.copy(os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so"), lib)
@@ -22,7 +22,7 @@ for co in sorted(glob.glob(lib + ".*gfx950")):
     text += subprocess.run([OBJDUMP, "-d", co], stdout=subprocess.PIPE, text=True).stdout
 lines = text.split("\n")
 name = "_Z19swg_diag_dyn_kernelILi%dELi" % K     # <K, waves the instantiation was compiled for, no edges, not wide>
-start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <%s\d+ELb%dELb%dE" % (name, EDGES, WIDE), l))
+start = next(i for i, l in enumerate(lines) if re.match(r"^[0-9a-f]+ <%s\d+ELb%dELi%dE" % (name, EDGES, WIDE), l))
 end = start + 1
 while end < len(lines) and not re.match(r"^[0-9a-f]+ <_Z", lines[end]):
     end += 1
