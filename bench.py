@@ -4,6 +4,11 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` (N > 1) started WITHOUT a launcher's environment starts its N ranks itself: before anything touches
+torch or HIP it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free> bench.py ...` as a child process, passes the child's one JSON line through and exits with
+its return code (`--spawn-dry-run` prints that command instead of running it).
+
 A step = one pass of the hot path (swg_search: int16 fill, saturation re-score when possible,
 top-K) over one resident synthetic database of the shapes of SURVEY 8d.
 
@@ -56,8 +61,13 @@ CONFIGS = {
     2: dict(lq=367, n=100000, matrix="PAM250"),
     3: dict(lq=500, n=570000, matrix="BLOSUM62"),
     4: dict(lq=3000, n=1250000, matrix="BLOSUM62", n_full=10000000),   # n: one GPU's eighth of the 10M-sequence DB
-    5: dict(lq=8192, n=100000, matrix="BLOSUM62", similar=0.01),
+    # one GPU's eighth of SURVEY 8d's 10M sequences, 1 % of them near-copies of the query
+    5: dict(lq=8192, n=1250000, matrix="BLOSUM62", similar=0.01, n_full=10000000),
 }
+# BASELINE.json names config 5 "forcing 16->32-bit rescore": its block carries, beside the library's own choice
+# (the wide int16 form, exact to 65535: nothing left to re-score), the same database with plain int16 cells,
+# every flagged sequence re-scored by the int32 work-queue kernel.
+CONFIG_LEGS = {5: (("rescore", {"wide16": 0}),)}
 HEADLINE = 3            # largest single-GPU configuration of BASELINE.json
 SHARDED = 4             # the configuration N > 1 runs, as one database dealt by bins
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak
@@ -106,6 +116,10 @@ def parse_args():
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--f16", type=int, default=-1, help="experiment: 0 = int16 cells only, 2 = f16 cells whenever the gap scores allow")
+    ap.add_argument("--wide16", type=int, default=-1, help="experiment: 0 = plain int16 cells + int32 re-score instead of the wide form")
+    ap.add_argument("--spawn-dry-run", action="store_true",
+                    help="--gpus N without a launcher: print the launch command as JSON instead of running it")
     return ap.parse_args()
 
 
@@ -120,9 +134,7 @@ class Env:
         # SWG_BENCH_FORCE_DIST=1: take the collective path even with one rank (rehearsal on a 1-GPU box)
         self.use_dist = self.world > 1 or os.environ.get("SWG_BENCH_FORCE_DIST") == "1"
         if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-            args.gpus = self.world
+            args.gpus = self.world  # (the launcher's world size rules; main() spawns the ranks when there is no launcher)
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -173,13 +185,18 @@ def make_context(env, q, sc):
         ctx.set_option("long_helps", 1)
     if a.prio_share >= 0:
         ctx.set_option("prio_share", a.prio_share)
+    if a.f16 >= 0:
+        ctx.set_option("f16", a.f16)
+    if a.wide16 >= 0:
+        ctx.set_option("wide16", a.wide16)
     return ctx
 
 
-def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclusive_leg=False, cpu_leg=False):
+def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclusive_leg=False, cpu_leg=False, legs=()):
     """One configuration: generate, pack, upload, warm up, time exactly `steps` steps between fences.
     sharded: the database is ONE global database dealt by bins over the ranks (strong scaling), else an
-    independent database on this rank.  Returns the block dict (rank 0) or None."""
+    independent database on this rank.  legs: ((name, {option: value}), ...): the same resident database timed
+    again with those options set (block[name]).  Returns the block dict (rank 0) or None."""
     a, swg = env.args, env.swg
     cfg = dict(CONFIGS[cnum])
     if a.lq:
@@ -244,27 +261,42 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
         while pending:
             record(*finish(pending.pop(0)))
 
-    run_steps(warmup, lambda hits, st: None)
-    fill_ms, total_ms, lasts, last_hits = [], [], [], []
+    def timed(n_steps, n_warm):
+        """n_warm untimed steps, then exactly n_steps between fences: (elapsed s, fill ms, total ms, stats, last hits)"""
+        run_steps(n_warm, lambda hits, st: None)
+        f_ms, t_ms, sts, hits_box = [], [], [], []
 
-    def record(hits, st):
-        fill_ms.append(st["fill_ms"])
-        total_ms.append(st["total_ms"])
-        lasts.append(st)
-        last_hits[:] = [hits]
+        def record(hits, st):
+            f_ms.append(st["fill_ms"])
+            t_ms.append(st["total_ms"])
+            sts.append(st)
+            hits_box[:] = [hits]
 
-    env.fence()
-    t0 = time.perf_counter()
-    run_steps(steps, record)
-    env.fence()
-    elapsed = time.perf_counter() - t0
+        env.fence()
+        t0 = time.perf_counter()
+        run_steps(n_steps, record)
+        env.fence()
+        return time.perf_counter() - t0, f_ms, t_ms, sts, hits_box
+
+    elapsed, fill_ms, total_ms, lasts, last_hits = timed(steps, warmup)
     last = lasts[-1]
+    elapsed_own = elapsed
 
     torch, dist = env.torch, env.dist
+    per_rank = None
     if env.use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own timed region and mean fill time, so that an uneven deal of the bins would show
+        mine = torch.tensor([elapsed_own * 1e3 / steps, float(np.mean(fill_ms)), float(db.residues)], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros(3, dtype=torch.float64, device="cuda") for _ in range(env.world)]
+        dist.all_gather(allr, mine)
+        allr = np.array([r.cpu().numpy() for r in allr])
+        per_rank = {"ms_per_step": {"min": round(float(allr[:, 0].min()), 4), "max": round(float(allr[:, 0].max()), 4)},
+                    "fill_ms": {"min": round(float(allr[:, 1].min()), 4), "max": round(float(allr[:, 1].max()), 4),
+                                "by_rank": [round(float(v), 4) for v in allr[:, 1]]},
+                    "residues": {"min": int(allr[:, 2].min()), "max": int(allr[:, 2].max())}}
     if sharded:
         cells_total = float(lq) * float(residues_total)          # ONE database, whatever the number of ranks
     elif env.use_dist:
@@ -282,39 +314,8 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
     block = None
     if env.rank == 0:
         gcups = cells_total * steps / elapsed / 1e9
-        # a query of several passes is one launch of the fill kernel per pass: the roofline figures are per
-        # launch (what rocprofv3's per-kernel average and the PMC counters are), so the step's fill time
-        # and its algorithmic bytes are divided by the number of launches
-        launches = max(1, int(last["fill_launches"])) if last["engine"] == 2 and last["path_bits"] == 16 and last["work_queue"] else 1
+        roofline, dtype = roofline_of(a, last, fill_ms, cells_local, cnum, sharded)
         step_fill_ms = float(np.mean(fill_ms))
-        k_ms = step_fill_ms / launches
-        bytes_alg = int(last["bytes_alg"]) // launches
-        achieved = bytes_alg / (k_ms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(a.traffic_json):
-            try:
-                tj = json.load(open(a.traffic_json))
-                # (counters are collected per configuration as bench.py --config C runs it; the whole-database form
-                # of config 4 has no measurement of its own: null rather than the share's figure)
-                traffic = tj.get("config%d%s" % (cnum, "_whole" if sharded else ""), {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # The binding roof is integer VALU issue, reported beside the (by construction tiny) HBM
-        # fraction.  5 packed instructions per cell (10 per two cells).  The hardware issues one wave64
-        # packed instruction per SIMD every 4 cycles (16 lanes per cycle) = the peak used for the
-        # fraction; an isolated instruction stream measures 4.4-4.56 cycles with 4 waves per SIMD
-        # (tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt), the fill kernels get to 4.26.
-        ops_per_cell = 5.0 if last["path_bits"] == 16 else 12.0
-        simds = 256 * 4
-        kernel_gcups = cells_local / (step_fill_ms * 1e-3) / 1e9
-        peak_issue = simds * 64 / 4.0 * 2.4e9 / ops_per_cell / 1e9
-        peak_microbench = simds * 64 / 4.56 * 2.35e9 / ops_per_cell / 1e9
-        if last["engine"] == 2 and last["path_bits"] == 16:
-            kname = ("swg_diag_dyn_kernel<%d>" if last["work_queue"] else "swg_diag_kernel<%d>") % last["cols_per_wave"]
-        elif last["engine"] == 2:
-            kname = "swg_diag32_kernel"
-        else:
-            kname = "swg_fill_kernel<CellsI%d>" % last["path_bits"]
         if sharded:
             workload = ("config %d: 1 query (%d aa) vs ONE %d-seq synthetic protein DB dealt by bins over %d GPU(s), "
                         "%s, gaps -2/-1, global top-%d by one RCCL all-reduce" % (cnum, lq, n, env.world, cfg["matrix"], K))
@@ -323,46 +324,129 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
                         % (cnum, lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], K))
             if cnum == 4 and not n_override:
                 workload += " (one GPU's eighth of the 10M-sequence database)"
+            if cfg.get("similar"):
+                workload += ", %g %% of the sequences near-copies of the query (5 %% substitutions)" % (100 * cfg["similar"])
         block = {
             "value": round(gcups, 3), "unit": "GCUPS", "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "dtype": "int16" if last["path_bits"] == 16 else "int32",
-            "config": {
+            "dtype": dtype,
+            "config": dict({
                 "workload": workload, "lq": lq, "n_seqs": n, "n_seqs_this_gpu": int(db.count),
-                "residues_total": int(residues_total), "residues_this_gpu": residues, "matrix": cfg["matrix"],
-                "cols_per_wave": last["cols_per_wave"], "waves": last["waves"], "passes": last["passes"],
-                "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
-                "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
-                "streams": last["streams"], "long_pairs": last["long_pairs"],
-                "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],
-                "work_queue": bool(last["work_queue"]), "classes_overlapped": last["classes_overlapped"],
-                "cells_padded_over_real": round(last["cells_padded"] / max(1, last["cells"]), 4),
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
-                "launches_per_step": launches,
-                "binding_roof": {"bound": "valu_issue", "kernel_gcups": round(kernel_gcups, 2),
-                                 "instr_per_cell": ops_per_cell,
-                                 "cycles_per_wave_instr": 4.0, "clock_ghz": 2.4,
-                                 "peak_gcups_issue": round(peak_issue, 1),
-                                 "frac_of_issue_peak": round(kernel_gcups / peak_issue, 4),
-                                 "peak_gcups_microbenchmark": round(peak_microbench, 1)},
-            },
+                "residues_total": int(residues_total), "residues_this_gpu": residues, "matrix": cfg["matrix"]},
+                **plan_of(last)),
+            "roofline": roofline,
             "kernel_ms": {"fill": round(step_fill_ms, 4), "search_total": round(float(np.mean(total_ms)), 4),
-                          "rescore": round(float(last["rescore_ms"]), 4), "topk_host": round(float(last["topk_ms"]), 4)},
+                          "rescore": round(float(np.mean([st["rescore_ms"] for st in lasts])), 4),
+                          "topk_host": round(float(last["topk_ms"]), 4)},
             "setup_s": {"generate": round(t_gen, 3), "pack": round(t_pack, 3)},
         }
+        if per_rank is not None:
+            block["per_rank"] = per_rank
         if verify is not None:
             block["verify"] = verify
+    # the same resident database again under other options (e.g. config 5 with the flagged-int32 re-score instead
+    # of the wide form): timed like the main leg, every score checked against the main leg's through the top-K
+    for name, opts in legs:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.search(db, want_scores=False, k=K)           # plans (and, with hints unknown, learns) outside the timed region
+        l_steps = max(2, steps)
+        l_elapsed, l_fill, l_total, l_sts, l_hits = timed(l_steps, min(warmup, 2))
+        if env.rank == 0:
+            l_roof, l_dtype = roofline_of(a, l_sts[-1], l_fill, cells_local, cnum, sharded)
+            block[name] = {"options": dict(opts), "value": round(cells_total * l_steps / l_elapsed / 1e9, 3), "unit": "GCUPS",
+                           "steps": l_steps, "ms_per_step": round(l_elapsed / l_steps * 1e3, 4), "dtype": l_dtype,
+                           "n_rescored": int(l_sts[-1]["n_rescored"]), "plan": plan_of(l_sts[-1]), "roofline": l_roof,
+                           "kernel_ms": {"fill": round(float(np.mean(l_fill)), 4),
+                                         "rescore": round(float(np.mean([st["rescore_ms"] for st in l_sts])), 4),
+                                         "search_total": round(float(np.mean(l_total)), 4)},
+                           "top_k_equals_main_leg": list(l_hits[0]) == list(last_hits[0])}
+            if not block[name]["top_k_equals_main_leg"]:
+                raise SystemExit("bench.py: leg %s returned another top-K than the main leg" % name)
+    if env.rank == 0:
         if host_inclusive_leg and env.world == 1 and not a.no_host_inclusive:
             block["host_inclusive"] = host_inclusive(env, ctx, flat, off, K, cells_local)
-        if cpu_leg and env.world == 1 and not a.no_cpu_baseline:
+        if cpu_leg and not a.no_cpu_baseline:
             block["cpu_baseline"] = cpu_baseline(swg, q, flat, off, sc, lq)
     db.close()
     ctx.close()
     return block
+
+
+def plan_of(last):
+    """What the library chose for a search, from its stats record."""
+    return {"cols_per_wave": last["cols_per_wave"], "waves": last["waves"], "passes": last["passes"],
+            "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
+            "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
+            "cells": {0: "packed int16", 1: "packed int16, wide form (to 65535)",
+                      2: "packed f16, three-operand maxima (exact below 2048; above: int32 re-score)"}.get(last["cell_form"])
+                     if last["path_bits"] == 16 else "int32",
+            "streams": last["streams"], "long_pairs": last["long_pairs"],
+            "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],
+            "work_queue": bool(last["work_queue"]), "classes_overlapped": last["classes_overlapped"],
+            "cells_padded_over_real": round(last["cells_padded"] / max(1, last["cells"]), 4)}
+
+
+def _traffic_table(path):
+    """profiles/traffic.json (HBM bytes per launch from the PMC counters of an earlier run of the same command,
+    tools/profile_bench.sh) and a short digest of the file, so that the line says where the figure comes from."""
+    try:
+        raw = open(path, "rb").read()
+        import hashlib
+        return json.loads(raw), "%s@sha256:%s" % (os.path.relpath(path, ROOT), hashlib.sha256(raw).hexdigest()[:16])
+    except Exception:
+        return {}, None
+
+
+def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
+    """The `roofline` object of one leg, and its dtype.  A query of several passes is one launch of the fill
+    kernel per pass (times the segments of a very large database): the figures are per launch -- what rocprofv3's
+    per-kernel average and the PMC counters are -- so the step's fill time and its algorithmic bytes are divided
+    by the number of launches."""
+    q16 = last["engine"] == 2 and last["path_bits"] == 16
+    launches = max(1, int(last["fill_launches"])) if last["engine"] == 2 and last["work_queue"] else 1
+    step_fill_ms = float(np.mean(fill_ms))
+    k_ms = step_fill_ms / launches
+    bytes_alg = int(last["bytes_alg"]) // launches
+    achieved = bytes_alg / (k_ms * 1e-3) / 1e9
+    form = int(last["cell_form"]) if q16 else -1
+    # (counters are collected per configuration and cell form as bench.py --config C runs it; a leg without a
+    # measurement of its own gets null rather than a neighbour's figure)
+    table, source = _traffic_table(a.traffic_json)
+    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {2: "_f16"}.get(form, "") if q16 else "_int32")
+    traffic = table.get(key, {}).get("hbm_bytes_per_launch")
+    # The binding roof is VALU issue, reported beside the (by construction tiny) HBM fraction: one wave64 packed
+    # instruction per SIMD every 4 cycles (16 lanes per cycle) at 2.4 GHz.  Instructions per cell: 5 for the packed
+    # int16 cells (10 per column pair), 4.25 for the packed f16 cells (8.5), 8 for the int32 work-queue kernel,
+    # 12 for the term-by-term int32 kernels.  An isolated stream of packed instructions measures 4.4-4.56 cycles
+    # with 4 waves per SIMD (tools/valu_rate.hip); the fill kernels get to 4.05.
+    if q16:
+        ops_per_cell = 4.25 if form == 2 else 5.0
+        kname = ("swg_diag_dyn_kernel<K=%d,%s>" if last["work_queue"] else "swg_diag_kernel<K=%d,%s>") % (
+            last["cols_per_wave"], {0: "int16", 1: "wide", 2: "f16"}[form])
+    elif last["engine"] == 2 and last["work_queue"]:
+        ops_per_cell, kname = 8.0, "swg_diag32q_kernel<K=%d>" % last["cols_per_wave"]
+    elif last["engine"] == 2:
+        ops_per_cell, kname = 12.0, "swg_diag32_kernel"
+    else:
+        ops_per_cell = 5.0 if last["path_bits"] == 16 else 12.0
+        kname = "swg_fill_kernel<CellsI%d>" % last["path_bits"]
+    simds = 256 * 4
+    kernel_gcups = cells_local / (step_fill_ms * 1e-3) / 1e9
+    peak_issue = simds * 64 / 4.0 * 2.4e9 / ops_per_cell / 1e9
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "traffic_source": (source + "#" + key) if traffic is not None else None,
+        "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
+        "launches_per_step": launches,
+        "binding_roof": {"bound": "valu_issue", "kernel_gcups": round(kernel_gcups, 2),
+                         "instr_per_cell": ops_per_cell, "cycles_per_wave_instr": 4.0, "clock_ghz": 2.4,
+                         "peak_gcups_issue": round(peak_issue, 1),
+                         "frac_of_issue_peak": round(kernel_gcups / peak_issue, 4)},
+    }
+    dtype = ("f16" if form == 2 else "int16") if last["path_bits"] == 16 else "int32"
+    return roofline, dtype
 
 
 def verify_topk(env, ctx, db, q, sc, flat, off, index, K, merger, timed_hits):
@@ -537,7 +621,9 @@ def cpu_baseline(swg, q, flat, off, sc, lq):
         return {"value": round(runs[best], 3), "unit": "GCUPS", "cores": int(best), "kind": "reference",
                 "cpu_model": model, "one_thread_gcups": round(one_thread, 3),
                 "sample": "%d of %d 16-record batches of the same DB (%.3g real cells; one thread: every 8th of them), "
-                          "reference alignment_fill_matrices under its OpenMP dynamic dispatch, fill region only; "
+                          "reference alignment_fill_matrices under its OpenMP dynamic dispatch, fill region only, built by "
+                          "oracle/Makefile with -O3 -march=x86-64-v3 -mavx2 -fopenmp (the reference's Makefile says -march=native: "
+                          "the library is built off the GPU box, and the kernel is explicit AVX2 intrinsics either way); "
                           "this process may use %d CPUs of the host's %d hardware threads; GCUPS by threads: %s"
                           % (len(batches), groups, cells, share, hw,
                              ", ".join("%d: %.1f" % (t, v) for t, v in sorted(runs.items())))}
@@ -561,7 +647,7 @@ def line_from(block, env, scaling):
            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": block["dtype"],
            "data": "synthetic", "config": block["config"], "roofline": block["roofline"],
            "kernel_ms": block["kernel_ms"]}
-    for k in ("verify", "host_inclusive", "cpu_baseline"):
+    for k in ("verify", "host_inclusive", "cpu_baseline", "per_rank"):
         if k in block:
             out[k] = block[k]
     return out
@@ -580,9 +666,49 @@ def emit(line):
         os.write(_REAL_STDOUT, data)
 
 
+def spawn_command(args, argv, port):
+    """The launch `--gpus N` makes for itself when no launcher has set RANK / WORLD_SIZE: one rank per GPU of this
+    node under torch.distributed.run (its children are fresh processes: nothing here has touched torch or HIP yet)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [
+                x for x in argv if x != "--spawn-dry-run"]
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """Runs the ranks as child processes, passes their one JSON line through and returns their exit code."""
+    import subprocess
+    cmd = spawn_command(args, argv, free_port())
+    if args.spawn_dry_run:
+        print(json.dumps({"spawn": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (the host driver supports dmabuf IPC only: RCCL needs this)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)    # stderr passes straight through
+    out, _ = proc.communicate()
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if proc.returncode == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: the ranks printed %d JSON lines instead of one\n" % len(lines))
+        return 1
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return proc.returncode
+
+
 def main():
     global _REAL_STDOUT
     args = parse_args()
+    # (SWG_BENCH_FORCE_SPAWN=1: also for one GPU -- with SWG_BENCH_FORCE_DIST=1 that is the whole N > 1 path,
+    # launcher, RCCL communicator and relay included, rehearsed on a one-GPU box)
+    if (args.gpus > 1 or os.environ.get("SWG_BENCH_FORCE_SPAWN") == "1") and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     # Libraries chat on stdout (RCCL prints a version banner at communicator creation): everything but the
     # result line goes to stderr, at file-descriptor level, so that stdout carries exactly one JSON line.
     sys.stdout.flush()
@@ -594,11 +720,12 @@ def main():
         # one global database dealt by bins; total work fixed as the number of GPUs grows
         cnum = args.config or SHARDED
         n_full = args.nseq or CONFIGS[cnum].get("n_full", CONFIGS[cnum]["n"])
-        block = run_config(env, cnum, K, W, sharded=True, n_override=n_full)
+        block = run_config(env, cnum, K, W, sharded=True, n_override=n_full, cpu_leg=True)
         if env.rank == 0:
             emit(line_from(block, env, "strong"))
     elif args.config:
-        block = run_config(env, args.config, K, W, host_inclusive_leg=True, cpu_leg=True)
+        block = run_config(env, args.config, K, W, host_inclusive_leg=True, cpu_leg=True,
+                           legs=CONFIG_LEGS.get(args.config, ()))
         out = line_from(block, env, "strong")
         out["configs"] = {str(args.config): {k: v for k, v in block.items() if k not in ("cpu_baseline", "host_inclusive")}}
         emit(out)
@@ -612,7 +739,7 @@ def main():
         if not args.only_headline:
             blocks["2"] = run_config(env, 2, K, W, host_inclusive_leg=True)
             blocks["4"] = run_config(env, 4, max(2, K // 5), min(W, 2))
-            blocks["5"] = run_config(env, 5, max(2, K // 4), min(W, 2))
+            blocks["5"] = run_config(env, 5, 2, 1, legs=CONFIG_LEGS[5])
             if "host_inclusive" in blocks["2"]:
                 out["host_inclusive"] = blocks["2"]["host_inclusive"]      # quoted on config 2, as in round 1
             if not args.no_scaling_reference:

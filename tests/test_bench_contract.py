@@ -20,7 +20,7 @@ def _check_block(b, n_gpus=1):
     # value = cells of the WHOLE database * steps / elapsed: consistent with ms_per_step and the workload
     cells = b["config"]["lq"] * b["config"]["residues_total"]
     assert abs(b["value"] - cells / (b["ms_per_step"] * 1e-3) / 1e9) < 0.01 * b["value"]
-    assert b["unit"] == "GCUPS" and b["dtype"] in ("int16", "int32")
+    assert b["unit"] == "GCUPS" and b["dtype"] in ("int16", "int32", "f16")
     assert r["kernel_ms"] * r.get("launches_per_step", 1) <= b["ms_per_step"] * 1.02
     assert b.get("verify", {"ok": True})["ok"] is True
 
@@ -56,8 +56,18 @@ def test_bench_help_and_launch_rule_need_no_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
-    # N > 1 without a launcher is refused before anything touches a device
+    # N > 1 without a launcher: bench.py starts its ranks itself, as child processes of a parent that has not
+    # touched torch or HIP -- the command it would run (nothing is launched here)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
-    assert r.returncode != 0 and "torch.distributed.run" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--spawn-dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout)["spawn"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    # under a launcher (RANK / WORLD_SIZE set) it does not spawn again
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"RANK" not in os.environ and "WORLD_SIZE" not in os.environ' in src
