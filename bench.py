@@ -379,7 +379,7 @@ def plan_of(last):
             "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
             "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
             "cells": {0: "packed int16", 1: "packed int16, wide form (to 65535)",
-                      2: "packed f16, three-operand maxima (exact below 2048; above: int32 re-score)"}.get(last["cell_form"])
+                      2: "packed f16, three-operand maxima (exact below 4096; above: int32 re-score)"}.get(last["cell_form"])
                      if last["path_bits"] == 16 else "int32",
             "streams": last["streams"], "long_pairs": last["long_pairs"],
             "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],

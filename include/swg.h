@@ -65,15 +65,15 @@ typedef struct swg_stats {
     uint64_t cells;         /* lq * sum(len_i): real cells, what GCUPS counts */
     uint64_t cells_padded;  /* cells actually computed (bin + strip padding) */
     uint64_t bytes_alg;     /* algorithmic HBM bytes of the fill */
-    uint64_t n_rescored;    /* sequences re-scored in int32 after int16 saturation */
+    uint64_t n_rescored;    /* sequences re-scored in int32 after reaching the 16-bit cells' ceiling */
     double fill_ms;         /* 16-bit fill kernel (or the int32 fill when forced) */
     double rescore_ms;      /* overflow collection + int32 re-score */
     double topk_ms;         /* device top-K selection */
     double total_ms;        /* first kernel start .. last kernel end */
     int32_t path_bits;      /* 16 or 32: arithmetic of the main fill */
-    int32_t cols_per_wave;  /* K: query columns held in registers per wavefront */
-    int32_t waves;          /* W: wavefronts of one systolic workgroup */
-    int32_t passes;         /* query passes (ceil(lq / (W*K))) */
+    int32_t cols_per_wave;  /* K: query columns held in registers per wavefront (systolic) / per lane (diagonal) */
+    int32_t waves;          /* W: wavefronts of one workgroup (systolic: chained over the query) */
+    int32_t passes;         /* query passes: systolic ceil(lq / (W*K)), diagonal ceil(lq / (group_lanes*K)) */
     int32_t workgroups;     /* grid size of the fill */
     int32_t engine;         /* 1 systolic (waves chained over the query), 2 diagonal (lane groups) */
     int32_t group_lanes;    /* diagonal engine: lanes sharing one pair of sequences (16/32/64) */
@@ -93,7 +93,7 @@ typedef struct swg_stats {
      * pass of a very large database is cut into; 1 for a query of one pass */
     int32_t fill_launches;
     /* the cells the 16-bit fill ran on: 0 packed int16 (scores to 32767), 1 the wide int16 form (to 65535),
-     * 2 packed f16 with gfx950's three-operand maxima (exact below 2048; a sequence that reaches it is
+     * 2 packed f16 with gfx950's three-operand maxima (exact below 4096; a sequence that reaches it is
      * flagged and re-scored in int32 like an int16 saturation) */
     int32_t cell_form;
 } swg_stats;
@@ -110,9 +110,11 @@ int swg_abi_version(void);
 
 /* Tuning / test switches.  Keys: "force_bits" (0 auto | 16 | 32),
  * "engine" (0 auto | 1 systolic | 2 diagonal; int16 path only),
- * "cols_per_wave" (0 auto | query columns a lane keeps in registers, multiple of 4),
+ * "cols_per_wave" (0 auto | systolic: 16, 24, 32 or 48 columns per wavefront; diagonal: 2..32 columns per lane),
  * "max_waves" (0 auto | systolic: waves chained over the query, 1..16; diagonal:
- * waves per workgroup, multiple of 4), "group_lanes" (0 auto | 16 | 32 | 64),
+ * waves per workgroup, 4, 8, 12 or 16), "group_lanes" (0 auto | 16 | 32 | 64; with force_bits = 32 a forced
+ * cols_per_wave x group_lanes whose int32 profile does not fit LDS is replaced by the library's pick, which
+ * swg_stats reports),
  * "long_split" (-1 off | 0 auto | rows above which a pair joins the long class),
  * "autotune" (1 default: on the first search of a query length the few geometries the cost model
  * ranks best are timed on the device and the fastest is kept for that database | 0 model only),
@@ -123,7 +125,11 @@ int swg_abi_version(void);
  * "prio_share" (percent of a lane group's mean share above which a bulk pair runs at raised
  * priority; default 150), "wide16" (1 default: when the query is long enough for a score to pass
  * 32767 the diagonal engine runs its wide form, exact to 65535, and only scores beyond that are
- * re-scored in int32 | 0: plain int16 and int32 re-score from 32767), "side_readout" (1 default:
+ * re-scored in int32 | 0: plain int16 and int32 re-score from 32767), "f16" (1 default: the diagonal engine's
+ * 16-bit fill runs on packed-f16 cells -- gfx950's three-operand maxima, 8.5 instead of 10 instructions per
+ * column pair, exact below 4096, every sequence that reaches 4096 flagged and re-scored in int32 -- unless the
+ * query is long enough for scores beyond 32767 or this database has flagged more than 2 % of its rows for this
+ * query | 0: int16 cells only | 2: f16 cells whenever the gap magnitudes are at most 2048), "side_readout" (1 default:
  * top-K selection and read-out of a search run on their own stream, beside the fill of the search
  * queued next). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
@@ -182,8 +188,8 @@ const uint32_t *swg_db_order(const swg_db *db);
  *               ORIGINAL database index; only this shard's entries are written.
  *   topk_out/k  NULL/0, or room for k hits of this shard (fewer are written
  *               when the shard is smaller; *n_hits tells how many).
- * Scores are exact int32 local-alignment maxima: the int16 kernel flags every
- * sequence whose score saturates and those are re-scored in int32. */
+ * Scores are exact int32 local-alignment maxima: the 16-bit kernels flag every
+ * sequence whose score reaches their ceiling and those are re-scored in int32. */
 int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out,
                swg_hit *topk_out, size_t k, size_t *n_hits, swg_stats *stats);
 

@@ -149,6 +149,12 @@ extern "C" void swg_destroy(swg_ctx *ctx)
         (void)hipHostFree(sl.h_counters);
         (void)hipHostFree(sl.h_scores);
     }
+    if (ctx->b16.db) swg_db_free(ctx->b16.db);
+    (void)hipHostFree(ctx->b16.h_stage);
+    (void)hipHostFree(ctx->b16.h_meta);
+    (void)hipFree(ctx->b16.d_stage);
+    (void)hipFree(ctx->b16.d_pair_src);
+    (void)hipFree(ctx->b16.d_pair_len);
     for (int i = 0; i < 4; ++i) {
         (void)hipHostFree(ctx->h_query_stage[i]);
         if (ctx->ev_query_stage[i]) (void)hipEventDestroy(ctx->ev_query_stage[i]);
@@ -394,6 +400,8 @@ extern "C" int swg_db_upload(swg_ctx *ctx, swg_db *db)
 static int ensure_bins(swg_ctx *ctx, swg_db *db)
 {
     if (db->d_packed || db->n_bins == 0) return SWG_OK;
+    if (db->tokens_only)
+        return swg_set_ctx_error(ctx, SWG_ERR_STATE, "this search needs the bin image, which a database built from 16-lane batches does not have");
     const size_t nb = db->n_bins;
     const uint64_t dwords = db->bin_off[nb - 1] + (uint64_t)db->bin_nblk[nb - 1] * SWG_BIN;
     HIP_TRY(ctx, hipMalloc(&db->d_bin_off, nb * 8));
@@ -690,12 +698,18 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
     for (int c = 0; c < wk.n_classes; ++c) {
         const SwgDiagPlan &pl = wk.plan[c];
         if (!diag_class_is_dynamic(ctx, db, pl)) {
+            if (db->tokens_only)
+                return swg_set_ctx_error(ctx, SWG_ERR_STATE, "this search needs fixed streams, which a database built from 16-lane batches does not have");
             int rc = ensure_diag_layout(ctx, db, c, pl, wk.pair_begin[c], wk.pair_end[c]);
             if (rc != SWG_OK) return rc;
-        } else if (pl.npass > 1 && !db->ptok.d_edge[0]) {
+        } else if (pl.npass > 1 && (!db->ptok.d_edge[0] || db->ptok.edge_blocks < db->ptok.total_blocks)) {
+            (void)hipFree(db->ptok.d_edge[0]);
+            (void)hipFree(db->ptok.d_edge[1]);
+            db->ptok.d_edge[0] = db->ptok.d_edge[1] = nullptr;
             const size_t bytes = std::max<size_t>(8, (size_t)db->ptok.total_blocks * 4 * sizeof(uint2));
             HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[0], bytes));
             HIP_TRY(ctx, hipMalloc(&db->ptok.d_edge[1], bytes));
+            db->ptok.edge_blocks = db->ptok.total_blocks;
         }
         const int kp = swg_diag_padded_cols(pl.K);
         const uint32_t ncols = (uint32_t)(pl.npass * pl.G * kp);
@@ -1059,10 +1073,14 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
     if (npass > 1) {
         if (wk.n_classes != 1 || T.total_blocks >= (1ull << 28))
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "int32 multi-pass fill: plan not supported");
-        if (!T.d_edge32[0]) {
+        if (!T.d_edge32[0] || T.edge32_blocks < T.total_blocks) {
+            (void)hipFree(T.d_edge32[0]);
+            (void)hipFree(T.d_edge32[1]);
+            T.d_edge32[0] = T.d_edge32[1] = nullptr;
             const size_t bytes = std::max<size_t>(8, (size_t)T.total_blocks * 4 * 2 * sizeof(int2));
             HIP_TRY(ctx, hipMalloc(&T.d_edge32[0], bytes));
             HIP_TRY(ctx, hipMalloc(&T.d_edge32[1], bytes));
+            T.edge32_blocks = T.total_blocks;
         }
     }
     for (int c = 0; c < wk.n_classes; ++c) {
@@ -1358,7 +1376,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     const uint64_t score_bound = std::min<uint64_t>(qbound, std::min<uint64_t>(lq, longest) * (uint64_t)smax);
     bool wide = bits == 16 && score_bound >= 32767ull && ctx->opt_engine != 1 && ctx->opt_wide != 0;
     // The packed-f16 cells (three-operand maxima, 8.5 instead of 10 instructions per column pair) are exact
-    // while scores stay below 2048; a sequence that reaches it is flagged and re-scored in int32.  They are the
+    // while scores stay below 4096; a sequence that reaches it is flagged and re-scored in int32.  They are the
     // first step whenever the gap magnitudes are f16 integers and the query is not so long that scores are
     // expected far beyond (where the wide form is exact on its own) -- unless this database has shown, for this
     // query, that a good part of its rows gets flagged ("f16" option: 0 never, 2 regardless of both).
@@ -1437,15 +1455,15 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // the f16 cells: every class on the work queue, and a re-score path for what they flag
     bool use_f16 = want_f16 && use_diag;
     for (int c = 0; use_f16 && c < wk.n_classes; ++c) use_f16 = diag_class_is_dynamic(ctx, db, wk.plan[c]);
-    if (q32_ok && (bits == 32 || score_bound >= (use_f16 ? 2048ull : wide ? 65535ull : 32767ull))) {
+    if (q32_ok && (bits == 32 || score_bound >= (use_f16 ? 4096ull : wide ? 65535ull : 32767ull))) {
         if ((rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
         SwgDiagWork probe;
         q32_ok = db->ptok.ok && q32_list_plan(ctx, lq, 1, &probe) &&
                  (probe.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28)); // (32-bit edge indices)
     }
-    if (use_f16 && score_bound >= 2048ull && !q32_ok) use_f16 = false;
+    if (use_f16 && score_bound >= 4096ull && !q32_ok) use_f16 = false;
     for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].f16 = use_f16 ? 1 : 0;
-    const int32_t ceiling = use_f16 ? 2048 : wide ? 65535 : 32767;
+    const int32_t ceiling = use_f16 ? 4096 : wide ? 65535 : 32767;
     const SwgDiagPlan &dpl = wk.plan[0];
     const bool may_saturate = bits == 16 && score_bound >= (uint64_t)ceiling;
     if (may_saturate) {
@@ -1461,6 +1479,27 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     if (bits == 32 && q32_ok) {
         use_q32 = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves, ctx->opt_long_split,
                                      ctx->opt_workgroups == 0, true, &wk32) > 0 && q32_plan_fits(wk32, lq);
+        if (!use_q32 && ctx->opt_cols > 0 && ctx->opt_group > 0) {
+            // a forced geometry that needs several passes (or whose long class did not fit): one class of exactly
+            // that geometry, a launch per pass -- if its int32 profile fits LDS; otherwise the library's own pick
+            // below, which swg_stats reports
+            for (int v = 0; v < swg_num_diag_variants() && !use_q32; ++v) {
+                const int K = swg_diag_variant_info(v).K, G = (int)ctx->opt_group;
+                if (K != (int)ctx->opt_cols || swg_diag32q_lds_bytes(K, G, 4) > 160 * 1024) continue;
+                const size_t np = (lq + (size_t)G * K - 1) / ((size_t)G * K);
+                if (np > 64 || (np > 1 && db->ptok.total_blocks >= (1ull << 28))) continue;
+                wk32 = SwgDiagWork();
+                wk32.n_classes = 1;
+                wk32.plan[0].variant = v;
+                wk32.plan[0].K = K;
+                wk32.plan[0].G = G;
+                wk32.plan[0].W = 4;
+                wk32.plan[0].npass = (int)np;
+                wk32.pair_begin[0] = 0;
+                wk32.pair_end[0] = swg_db_pair_count(db);
+                use_q32 = true;
+            }
+        }
         if (!use_q32) {
             // the int16 planner's choice does not fit (LDS holds half as many int32 columns): fewest lanes that do
             use_q32 = q32_list_plan(ctx, lq, (uint32_t)std::min<size_t>(n_slots, 1u << 30), &wk32);
@@ -1891,9 +1930,26 @@ static void multi_deliver(const swg_db *db, const int32_t *h_scores, size_t n_sl
     }
 }
 
+static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queries, const uint64_t *q_offsets,
+                             size_t n_queries, int32_t *scores_out, swg_hit *topk_out, size_t k, size_t *n_hits,
+                             swg_stats *stats);
+
 extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *queries, const uint64_t *q_offsets,
                                 size_t n_queries, int32_t *scores_out, swg_hit *topk_out, size_t k, size_t *n_hits,
                                 swg_stats *stats)
+{
+    try { // no C++ exception crosses the ABI (the body sizes host vectors by the batch)
+        return search_multi_impl(ctx, db, queries, q_offsets, n_queries, scores_out, topk_out, k, n_hits, stats);
+    } catch (const std::bad_alloc &) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_search_multi: out of host memory");
+    } catch (const std::exception &e) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_search_multi: %s", e.what());
+    }
+}
+
+static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queries, const uint64_t *q_offsets,
+                             size_t n_queries, int32_t *scores_out, swg_hit *topk_out, size_t k, size_t *n_hits,
+                             swg_stats *stats)
 {
     if (!ctx || !db || (n_queries && (!queries || !q_offsets)))
         return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_multi: NULL argument");
@@ -2105,6 +2161,7 @@ extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *qu
     st.path_bits = 16;
     st.engine = 2;
     st.work_queue = 1;
+    st.classes_overlapped = -1; // (not measured for a batch)
     st.cols_per_wave = wk.plan[0].K;
     st.group_lanes = wk.plan[0].G;
     st.waves = wk.plan[0].W;
@@ -2123,8 +2180,205 @@ extern "C" int swg_search_multi(swg_ctx *ctx, const swg_db *db, const int8_t *qu
 // ---------------------------------------------------------------------------
 // reference-shaped replay (16-lane batches as alignment_fill_matrices gets them)
 // ---------------------------------------------------------------------------
+// The device route.  The batches go to the GPU as they are -- [max_len][16] table indices, copied end to end into
+// pinned staging by all cores and from there in one transfer -- and the pair tokens are built from that image on the
+// device: the two sequences of a pair are two adjacent lanes of one batch, so a row's two residues are two adjacent
+// bytes (swg_build_tokens16_kernel).  Nothing is un-transposed or re-coded on the host, and nothing is allocated or
+// freed per call once the buffers have grown to the size of the caller's macro-batches (round 2 rebuilt a whole
+// database per call: 26-34 ms of host work and hipFree around 2.5 ms of device time).  Returns 1 when the search
+// cannot take this route (options or gap scores that need the bin image): the caller falls back to the host route.
+static int fill_batches16_device(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches, size_t n_records,
+                                 const size_t *first_rec, double *fill_seconds, double *t_ms)
+{
+    typedef std::chrono::steady_clock clk;
+    const clk::time_point t0 = clk::now();
+    const bool fast_ok = ctx->gap_open <= 0 && ctx->gap_extend <= 0 && -(ctx->gap_open + ctx->gap_extend) <= 32767;
+    if (!fast_ok || ctx->opt_engine == 1 || ctx->opt_dynamic == 0 || !ctx->have_scoring || ctx->query.empty()) return 1;
+    for (const SwgSlot &sl : ctx->slots)
+        if (sl.busy) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_fill_batches16: searches are in flight on this context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SwgBatch16Cache &C = ctx->b16;
+    // batches longest first (the reference's caller passes them sorted: then this is the identity)
+    std::vector<uint32_t> bo(n_batches);
+    for (size_t b = 0; b < n_batches; ++b) bo[b] = (uint32_t)b;
+    bool sorted = true;
+    for (size_t b = 1; b < n_batches && sorted; ++b) sorted = batches[b].max_len <= batches[b - 1].max_len;
+    if (!sorted)
+        std::stable_sort(bo.begin(), bo.end(), [&](uint32_t x, uint32_t y) { return batches[x].max_len > batches[y].max_len; });
+    // sizes
+    size_t n_pairs = 0;
+    uint64_t stage_bytes = 0, total_blocks = 0, residues = 0, longest = 0;
+    for (size_t b = 0; b < n_batches; ++b) {
+        const swg_batch16 &bt = batches[b];
+        if (bt.max_len > 0x3FFFFFFFull) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_fill_batches16: batch %zu too long", b);
+        const size_t np = (bt.vector_size + 1) / 2;
+        n_pairs += np;
+        stage_bytes += (uint64_t)bt.max_len * 16u;
+        total_blocks += (uint64_t)np * ((2ull + bt.max_len + 3) / 4);
+        residues += (uint64_t)bt.vector_size * bt.max_len;
+        longest = std::max<uint64_t>(longest, bt.max_len);
+    }
+    if (n_pairs >= (1ull << 31) || total_blocks + 1 >= (1ull << 32)) return 1;
+    const size_t n_slots = (2 * n_pairs + SWG_BIN - 1) / SWG_BIN * SWG_BIN;
+    // ---- buffers: grown, never shrunk ---------------------------------------------------------
+    if (!C.db || n_slots > C.slots_cap || n_pairs > C.pairs_cap || total_blocks > C.blocks_cap || stage_bytes > C.stage_cap) {
+        if (C.db) swg_db_free(C.db);
+        C.db = nullptr;
+        (void)hipHostFree(C.h_stage);
+        (void)hipHostFree(C.h_meta);
+        (void)hipFree(C.d_stage);
+        (void)hipFree(C.d_pair_src);
+        (void)hipFree(C.d_pair_len);
+        C.h_stage = C.h_meta = nullptr;
+        C.d_stage = nullptr;
+        C.d_pair_src = nullptr;
+        C.d_pair_len = nullptr;
+        auto grow = [](uint64_t need, uint64_t have) { return std::max<uint64_t>(need + need / 4 + 64, have); };
+        C.slots_cap = (size_t)((grow(n_slots, C.slots_cap) + SWG_BIN - 1) / SWG_BIN * SWG_BIN);
+        C.pairs_cap = (size_t)grow(n_pairs, C.pairs_cap);
+        C.blocks_cap = grow(total_blocks, C.blocks_cap);
+        C.stage_cap = (size_t)grow(stage_bytes, C.stage_cap);
+        swg_db *db = new (std::nothrow) swg_db();
+        if (!db) return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of memory");
+        C.db = db;
+        db->tokens_only = true;
+        db->device = ctx->device;
+        db->n_bins = (uint32_t)(C.slots_cap / SWG_BIN); // (sizes the per-search output buffers)
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&C.h_stage), C.stage_cap, hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&C.h_meta), C.pairs_cap * 16 + 8 + C.slots_cap * 8, hipHostMallocDefault));
+        HIP_TRY(ctx, hipMalloc(&C.d_stage, C.stage_cap));
+        HIP_TRY(ctx, hipMalloc(&C.d_pair_src, C.pairs_cap * 8));
+        HIP_TRY(ctx, hipMalloc(&C.d_pair_len, C.pairs_cap * 4));
+        HIP_TRY(ctx, hipMalloc(&db->d_codes, 16)); // (marks the database resident; there are no residue bytes by rank)
+        HIP_TRY(ctx, hipMalloc(&db->d_lens, C.slots_cap * 4));
+        HIP_TRY(ctx, hipMalloc(&db->d_order, C.slots_cap * 4));
+        HIP_TRY(ctx, hipMalloc(&db->ptok.d_tok, (size_t)(C.blocks_cap + 1) * 16));
+        HIP_TRY(ctx, hipMalloc(&db->ptok.d_pair_off, (C.pairs_cap + 1) * 4));
+        int rb = select_bufs(ctx, db, 0);
+        if (rb != SWG_OK) return rb;
+    }
+    swg_db *db = C.db;
+    // ---- this call's database: ranks 2p, 2p+1 = lanes 2i, 2i+1 of a batch --------------------------------
+    uint64_t *pair_src = reinterpret_cast<uint64_t *>(C.h_meta);
+    uint32_t *pair_len = reinterpret_cast<uint32_t *>(C.h_meta + C.pairs_cap * 8);
+    uint32_t *h_lens = reinterpret_cast<uint32_t *>(C.h_meta + C.pairs_cap * 12);
+    uint32_t *h_order = h_lens + C.slots_cap;
+    try {
+        db->lens.assign(n_slots, 0u);
+        db->order.assign(n_slots, 0xFFFFFFFFu);
+        db->ptok.pair_blocks_prefix.assign(n_pairs + 1, 0u);
+    } catch (const std::exception &) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
+    }
+    std::vector<uint64_t> stage_off(n_batches);
+    {
+        uint64_t so = 0;
+        size_t p = 0;
+        uint32_t blocks = 0;
+        for (size_t k = 0; k < n_batches; ++k) {
+            const size_t b = bo[k];
+            const swg_batch16 &bt = batches[b];
+            stage_off[b] = so;
+            for (size_t i = 0; 2 * i < bt.vector_size; ++i, ++p) {
+                const bool has_y = 2 * i + 1 < bt.vector_size;
+                pair_src[p] = (so + 2 * i) | (has_y ? 0ull : 1ull << 63);
+                pair_len[p] = (uint32_t)bt.max_len;
+                db->lens[2 * p] = (uint32_t)bt.max_len;
+                db->order[2 * p] = (uint32_t)(first_rec[b] + 2 * i);
+                if (has_y) {
+                    db->lens[2 * p + 1] = (uint32_t)bt.max_len;
+                    db->order[2 * p + 1] = (uint32_t)(first_rec[b] + 2 * i + 1);
+                }
+                blocks += (uint32_t)((2ull + bt.max_len + 3) / 4);
+                db->ptok.pair_blocks_prefix[p + 1] = blocks;
+            }
+            so += (uint64_t)bt.max_len * 16u;
+        }
+    }
+    db->n_total = n_records;
+    db->n_local = 2 * n_pairs; // (an odd batch's missing lane is an empty slot in the middle: pairs stay batch-aligned)
+    db->n_bins = (uint32_t)(n_slots / SWG_BIN);
+    db->residues = residues;
+    db->max_nblk = (uint32_t)((longest + 3) / 4);
+    db->rows_padded = 0;
+    db->tuned.clear();
+    SwgPairTokens &T = db->ptok;
+    T.tried = T.ok = true;
+    T.total_blocks = total_blocks;
+    memcpy(h_lens, db->lens.data(), n_slots * 4);
+    memcpy(h_order, db->order.data(), n_slots * 4);
+    t_ms[0] = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    const clk::time_point t1 = clk::now();
+    {
+        const long long nb = (long long)n_batches;
+#pragma omp parallel for schedule(dynamic, 32) num_threads(swg_host_threads())
+        for (long long b = 0; b < nb; ++b) memcpy(C.h_stage + stage_off[b], batches[b].db_idx_t, (size_t)batches[b].max_len * 16u);
+    }
+    t_ms[1] = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
+    const clk::time_point t2 = clk::now();
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(C.d_stage, C.h_stage, stage_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(C.d_pair_src, pair_src, n_pairs * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(C.d_pair_len, pair_len, n_pairs * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(T.d_pair_off, T.pair_blocks_prefix.data(), (n_pairs + 1) * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(db->d_lens, h_lens, n_slots * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(db->d_order, h_order, n_slots * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(T.d_tok + total_blocks, 0, 16, s)); // the block of zeros behind the last pair
+    uint32_t *d_bad = reinterpret_cast<uint32_t *>(db->d_codes);
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 4, s));
+    HIP_TRY(ctx, swg_launch_build_tokens16(C.d_stage, C.d_pair_src, C.d_pair_len, T.d_pair_off, (uint32_t)n_pairs, total_blocks,
+                                           T.d_tok, d_bad, s));
+    // ---- the search itself (the cost model's geometry: this database is searched once) ----------------------
+    swg_stats st;
+    const auto keep_autotune = ctx->opt_autotune;
+    ctx->opt_autotune = 0;
+    int rc = search_begin(ctx, db, true, 0, &ctx->slots[0]);
+    if (rc == SWG_OK) {
+        ctx->slots[0].busy = true;
+        // (scores by record index: straight from the slot's pinned landing buffer, no int32 array in between)
+        rc = search_end(ctx, &ctx->slots[0], nullptr, nullptr, nullptr, &st);
+        ctx->slots[0].busy = false;
+    }
+    ctx->opt_autotune = keep_autotune;
+    if (rc != SWG_OK) return rc == SWG_ERR_STATE && strstr(ctx->err.c_str(), "built from 16-lane batches") ? 1 : rc;
+    uint32_t bad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, spin_sync(ctx, s));
+    if (bad) return swg_set_ctx_error(ctx, SWG_ERR_RESIDUE, "swg_fill_batches16: residue index outside 1..31 in a batch");
+    t_ms[2] = std::chrono::duration<double, std::milli>(clk::now() - t2).count();
+    const clk::time_point t3 = clk::now();
+    const int32_t *hs = ctx->slots[0].h_scores;
+    {
+        size_t p = 0;
+        for (size_t k = 0; k < n_batches; ++k) {
+            const swg_batch16 &bt = batches[bo[k]];
+            for (size_t i = 0; 2 * i < bt.vector_size; ++i, ++p) {
+                bt.max_scores[2 * i] = (int16_t)std::min<int32_t>(hs[2 * p], 32767);
+                if (2 * i + 1 < bt.vector_size) bt.max_scores[2 * i + 1] = (int16_t)std::min<int32_t>(hs[2 * p + 1], 32767);
+            }
+        }
+    }
+    t_ms[3] = std::chrono::duration<double, std::milli>(clk::now() - t3).count();
+    t_ms[4] = st.total_ms;
+    if (fill_seconds) *fill_seconds = st.total_ms * 1e-3;
+    return SWG_OK;
+}
+
+static int fill_batches16_impl(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches, double *fill_seconds);
+
 extern "C" int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches,
                                   double *fill_seconds)
+{
+    try { // no C++ exception crosses the ABI
+        return fill_batches16_impl(ctx, batches, n_batches, fill_seconds);
+    } catch (const std::bad_alloc &) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
+    } catch (const std::exception &e) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: %s", e.what());
+    }
+}
+
+static int fill_batches16_impl(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches, double *fill_seconds)
 {
     if (!ctx || (!batches && n_batches))
         return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_fill_batches16: NULL argument");
@@ -2149,6 +2403,26 @@ extern "C" int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size
     } catch (const std::exception &) {
         return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
     }
+    const size_t n_all = offsets.size() - 1;
+    if (n_all == 0) return SWG_OK;
+    {
+        double t_ms[5] = {0, 0, 0, 0, 0};
+        int rd = SWG_OK;
+        try {
+            rd = fill_batches16_device(ctx, batches, n_batches, n_all, first_rec.data(), fill_seconds, t_ms);
+        } catch (const std::exception &) {
+            return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
+        }
+        if (rd != 1) {
+            if (rd == SWG_OK && timing)
+                fprintf(stderr, "[swg_fill_batches16] %zu records, device route: tables %.2f ms, staging copy %.2f, upload + tokens + search + "
+                                "read-out %.2f (device, first kernel to last: %.2f), scores to the batches %.2f; wall %.2f\n",
+                        n_all, t_ms[0], t_ms[1], t_ms[2], t_ms[4], t_ms[3],
+                        std::chrono::duration<double, std::milli>(clk::now() - tp[0]).count());
+            return rd;
+        }
+    }
+    // the host route (searches the device route cannot take: positive gap scores, engine = 1, work_queue = 0)
     std::unique_ptr<int8_t[]> flat(new (std::nothrow) int8_t[std::max<uint64_t>(1, offsets.back())]);
     if (!flat) return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
     swg_untranspose_batches16(batches, n_batches, first_rec.data(), offsets.data(), flat.get());
@@ -2164,7 +2438,13 @@ extern "C" int swg_fill_batches16(swg_ctx *ctx, const swg_batch16 *batches, size
     tp[2] = clk::now();
     rc = swg_db_upload(ctx, db);
     tp[3] = clk::now();
-    std::vector<int32_t> scores(n, 0);
+    std::vector<int32_t> scores;
+    try {
+        scores.assign(n, 0);
+    } catch (const std::exception &) {
+        swg_db_free(db);
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
+    }
     swg_stats st;
     // (this database is searched exactly once: the cost model's geometry, no timed trials)
     const auto keep_autotune = ctx->opt_autotune;

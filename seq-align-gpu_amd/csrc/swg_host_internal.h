@@ -68,13 +68,14 @@ struct SwgPairTokens {
     uint32_t *d_pair_off = nullptr;
     uint2 *d_edge[2] = {nullptr, nullptr};    // multi-pass: (M,B) per row between consecutive passes, ping-pong
     int2 *d_edge32[2] = {nullptr, nullptr};   // the same for the int32 work-queue kernel: per row and per sequence of the pair
+    uint64_t edge_blocks = 0, edge32_blocks = 0; // token blocks the edge buffers were allocated for (a re-filled database may have grown)
     std::vector<uint32_t> pair_blocks_prefix; // host copy of pair_off
 };
 
 struct SwgDiagPlan {
     int variant = 0, K = 0, G = 0, npass = 0, W = 0, workgroups = 0;
     int wide = 0; // scores to 65535 (values biased by -32768)
-    int f16 = 0;  // packed-f16 cells with three-operand maxima: scores below 2048, anything above flagged and re-scored
+    int f16 = 0;  // packed-f16 cells with three-operand maxima: scores below 4096, anything above flagged and re-scored
     uint32_t n_streams = 0;
     size_t lds_bytes = 0;
     double est_ms = 0.0;
@@ -125,6 +126,9 @@ struct swg_db {
     // database full of close relatives of the query) that the int16 cells are the faster first step.
     long long sat_hint = -1;
     uint64_t f16_veto_epoch = 0;
+    // a database whose pair tokens were built straight from reference-shaped 16-lane batches
+    // (swg_fill_batches16): there are no residue bytes by sorted rank, so nothing that needs them can run
+    bool tokens_only = false;
     // device image (valid after swg_db_upload): the residue bytes and three words per slot; the pair
     // tokens (ptok) and the bin image are built FROM them on the device, the bins only when an
     // engine that reads them is used (swg_ensure_bins)
@@ -179,6 +183,19 @@ struct SwgSlot {
     size_t h_scores_cap = 0;        // entries
 };
 
+// What swg_fill_batches16 keeps between calls (the reference calls it once per macro-batch with buffers of
+// recurring size, src/alignment_cmdline.c:459-509): pinned staging for the batches as they are, their device
+// copy, and a database object whose device buffers are re-filled, grown only when a call needs more.
+struct SwgBatch16Cache {
+    swg_db *db = nullptr;
+    size_t slots_cap = 0, pairs_cap = 0, stage_cap = 0;
+    uint64_t blocks_cap = 0;
+    uint8_t *h_stage = nullptr, *d_stage = nullptr;   // the batches' [max_len][16] bytes, end to end
+    uint8_t *h_meta = nullptr;                        // pinned: pair sources, pair lengths, pair offsets, lengths, order
+    uint64_t *d_pair_src = nullptr;
+    uint32_t *d_pair_len = nullptr;
+};
+
 struct swg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -214,6 +231,7 @@ struct swg_ctx {
     uint64_t epoch = 1;               // bumps whenever scoring or query change
     uint32_t *d_scratch = nullptr;
     size_t d_scratch_cap = 0; // dwords
+    SwgBatch16Cache b16;
     SwgSlot slots[SWG_MAX_INFLIGHT];
     SwgSlot *cur = nullptr; // slot whose events the launch helpers record into
     int next_slot = 0;

@@ -187,11 +187,17 @@ int swg_diag_padded_cols(int K); // layout columns of a lane's slice
 hipError_t swg_launch_build_tokens(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
                                    const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint4 *d_tok,
                                    hipStream_t stream);
+// Pair tokens straight from reference-shaped batches ([max_len][16] int8 table indices, two adjacent lanes = one
+// pair): pair p reads its X residue of row j at stage[pair_src[p] + 16 j], its Y residue one byte further (bit 63
+// of pair_src: no Y, an odd lane count); *d_bad becomes non-zero if an index is outside 1..31.
+hipError_t swg_launch_build_tokens16(const uint8_t *d_stage, const uint64_t *d_pair_src, const uint32_t *d_pair_len,
+                                     const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint4 *d_tok,
+                                     uint32_t *d_bad, hipStream_t stream);
 hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code_off, const uint32_t *d_lens,
                                  const uint64_t *d_bin_off, const uint32_t *d_bin_nblk, uint32_t n_bins,
                                  uint32_t *d_packed, hipStream_t stream);
 
-// Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, 65535 in the wide form, 2048 for the
+// Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, 65535 in the wide form, 4096 for the
 // packed-f16 cells) to list.
 hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t stream);
 // d_lens / d_rows16 (or NULL): also adds up the flagged sequences' lengths, in units of 16 rows.

@@ -480,18 +480,24 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
 //     use the all-ones gap trick in this form and wipe the state explicitly.
 //  2  packed f16 with gfx950's three-operand maximum (v_pk_maximum3_f16): the floors are the third operand of
 //     the maxima that are needed anyway, M = max3(t, a, b) is one instruction instead of two and the running
-//     best takes two columns per instruction: 8.5 instructions per 2 cells.  Every value is an integer; f16
-//     holds integers exactly up to 2048, and sums of two such values round monotonically, so a pair whose
-//     computed best stays below 2048 has had every cell computed exactly; a pair that reaches 2048
-//     is flagged and re-scored.  G is kept unfloored (M - |go| may be negative; the max3 floors it where it is
-//     used).  Reset rows: gap magnitudes of 65504, the largest finite f16, clear every finite state in two rows;
-//     a lane whose best reached +inf (a score beyond 65504 in the making) is wiped explicitly.  The profile holds
-//     f16 bit patterns, -65504 for padding; no NaN can arise (no -inf exists, +inf meets only finite values).
+//     best takes two columns per instruction: 8.5 instructions per 2 cells.  Every value is an integer, and f16
+//     holds the integers of [-2048, 2048] exactly: a score v is held as v - 2048 (as the wide form biases by
+//     32768), so the cells are exact for scores 0 .. 4096.  Sums round monotonically beyond that range: a sum
+//     whose true value is above 2048 comes out >= 2048, one below -2048 comes out <= -2048 and is floored to
+//     -2048 (= score 0) like its true value.  So a pair whose computed best stays below 2048 (score 4096) has
+//     had every cell computed exactly; a pair that reaches it is flagged and re-scored.  G is kept
+//     unfloored (the max3 floors it where it is used).  Reset rows: gap magnitudes of 65504, the largest finite
+//     f16, clear every state below 32768 in two rows; a lane whose best got beyond that (a score far above the
+//     flag level in the making) is wiped explicitly.  The profile holds f16 bit patterns, -65504 for padding; no
+//     NaN can arise (-inf exists only as a transient diagonal sum that the floor replaces, +inf meets only finite
+//     values).
 #define SWG_F16_BIG 0x7BFF7BFFu  // 65504 in both halves
-#define SWG_F16_FLAG 0x6800u     // 2048.0: a score that reaches it is flagged
+#define SWG_F16_ZERO 0xE800E800u // -2048.0 in both halves: score 0
+#define SWG_F16_FLAG 0x6800u     // +2048.0 = score 4096: a pair that reaches it is flagged
+#define SWG_F16_CEILING 4096
 template <int K, int FORM = 0> struct CellsDiag {
     static constexpr bool WIDE = FORM == 1, F16 = FORM == 2;
-    static constexpr uint32_t ZERO = WIDE ? 0x80008000u : 0u;
+    static constexpr uint32_t ZERO = WIDE ? 0x80008000u : F16 ? SWG_F16_ZERO : 0u;
     DEVINL static uint32_t sub(uint32_t a, uint32_t b) { return F16 ? pk_sub_f16(a, b) : WIDE ? pk_sub_i16_sat(a, b) : pk_sub_u16_sat(a, b); }
     // A profile chunk is [32 residues][4 columns] int16 = 256 bytes; a lane's slice of the profile
     // is KP = K rounded up to whole chunks, the columns it works on are the first K (any K: G*K
@@ -523,10 +529,12 @@ template <int K, int FORM = 0> struct CellsDiag {
         mdl = (mdl & ~fm) | (ZERO & fm);
     }
 
-    // F16: all ones in lanes whose running best holds +inf in either half
-    DEVINL uint32_t best_is_inf() const
+    // F16: all ones in lanes whose running best is 32768 or more (+inf included) in either half.  Two reset rows
+    // clear what a pair leaves behind only up to 65504 - 2048 (a row subtracts 65504, the floor is -2048): a lane
+    // with more than that in it is wiped by hand, long before.
+    DEVINL uint32_t best_is_huge() const
     {
-        return 0u - (uint32_t)((((best & 0x7C007C00u) + 0x04000400u) & 0x80008000u) != 0u);
+        return 0u - (uint32_t)((((best & 0x78007800u) + 0x08000800u) & 0x80008000u) != 0u);
     }
 
     // as CellsI16::row, with per-lane gap magnitudes (all ones on reset rows).  ax / ay: 32-bit LDS
@@ -534,8 +542,9 @@ template <int K, int FORM = 0> struct CellsDiag {
     // pipeline with a depth of one chunk -- chunk c+1's profile reads are issued before chunk c's
     // arithmetic and nothing moves across the chunk boundary, so at most two chunks' words (8
     // registers) are in flight.  Left alone the scheduler hoists eight reads and K=24 spills.
+    // zero: F16 only: score 0 (SWG_F16_ZERO) in a register the caller keeps (a literal would be re-materialised per use)
     template <bool FENCED = false>
-    DEVINL uint2 row(uint32_t ax, uint32_t ay, uint32_t em, uint32_t eb, uint32_t go, uint32_t ge)
+    DEVINL uint2 row(uint32_t ax, uint32_t ay, uint32_t em, uint32_t eb, uint32_t go, uint32_t ge, uint32_t zero = 0u)
     {
         constexpr int NCH = KP / CH;
         uint32_t md = mdl;
@@ -562,8 +571,8 @@ template <int K, int FORM = 0> struct CellsDiag {
                 if (F16) {
                     const uint32_t t = pk_add_f16(md, s[u]);
                     md = M[k];
-                    const uint32_t a = pk_max3_f16(G[k], pk_sub_f16(A[k], ge), 0u);
-                    const uint32_t b = pk_max3_f16(gl, pk_sub_f16(bl, ge), 0u);
+                    const uint32_t a = pk_max3_f16(G[k], pk_sub_f16(A[k], ge), zero);
+                    const uint32_t b = pk_max3_f16(gl, pk_sub_f16(bl, ge), zero);
                     const uint32_t m = pk_max3_f16(t, a, b);
                     M[k] = m;
                     A[k] = a;
@@ -593,11 +602,15 @@ template <int K, int FORM = 0> struct CellsDiag {
     }
 };
 
-// integer score of a packed-f16 best (one half, as it comes out of the LDS maximum): flagged at 2048
-DEVINL int f16_score(uint32_t bits)
+// The LDS maximum of the f16 bests is taken on order-preserving 16-bit keys: a non-negative value's bits with the
+// sign bit set, a negative value's bits complemented (so 0 = below everything: an untouched slot).
+DEVINL uint32_t f16_key(uint32_t bits) { return (bits & 0x8000u) ? (~bits & 0xFFFFu) : (bits | 0x8000u); }
+// integer score of such a key: value + 2048, flagged (SWG_F16_CEILING) from +2048.0 up, +inf included
+DEVINL int f16_score(uint32_t key)
 {
-    if (bits >= SWG_F16_FLAG) return 2048;
-    return (int)(float)__builtin_bit_cast(_Float16, (unsigned short)bits);
+    if (key >= (0x8000u | SWG_F16_FLAG)) return SWG_F16_CEILING;
+    const uint32_t bits = (key & 0x8000u) ? (key & 0x7FFFu) : (~key & 0xFFFFu);
+    return (int)(float)__builtin_bit_cast(_Float16, (unsigned short)bits) + 2048;
 }
 
 template <int CTRL> DEVINL uint32_t dpp_zero(uint32_t src)
@@ -873,7 +886,7 @@ DEVINL uint32_t quad_bcast(uint32_t x, int r)
 // behind the leader) from the pair ring, and parks it when the row flagged IDLE -- sent once by a
 // leader that finds the queue empty -- reaches it.
 // FORM: the cells (see CellsDiag): 0 packed int16, 1 wide (scores to 65535; needs EDGES: a query that can pass
-// 32767 is long), 2 packed f16 with three-operand maxima (scores below 2048, anything above is flagged).
+// 32767 is long), 2 packed f16 with three-operand maxima (scores below 4096, anything above is flagged).
 template <int K, int MAXW, bool EDGES = false, int FORM = 0>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDynParams p)
 {
@@ -913,6 +926,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     CellsDiag<K, FORM> cells;
     cells.reset();
     uint32_t tok = 0u, m_out = Z, b_out = Z;
+    // F16 without edges: score 0 is not a zero bit pattern, so a lane without a DPP source (the leader) cannot be
+    // zero-filled.  The incoming edge lives in registers that are only ever written by the DPP move itself: the
+    // leader keeps the score-0 pattern they start with, without a v_mov per row (two of each: a row's M edge is
+    // still wanted as the next row's diagonal when the next edge arrives).
+    uint32_t em_rot[2] = {Z, Z}, eb_rot[2] = {Z, Z};
+    uint32_t zero_v = Z; // (F16: the floor operand of the maxima, kept in a register)
+    asm volatile("" : "+v"(zero_v));
     uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
     uint32_t nlast = 0u;               // last rows this lane has seen = position of its pair in the group's rings
     // Tokens: T0..T3 are the rows of the block being worked on.  Each is re-loaded with the same row of
@@ -1075,14 +1095,26 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
             }
             uint32_t em, eb;
             const int Gs = G16 ? 16 : opaque_uniform(G);
+            constexpr bool KEEP = F16 && !EDGES; // (see em_rot)
             if (G16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
-                em = EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, m_out) : dpp_zero<DPP_ROW_SHR1>(m_out);
-                eb = EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, b_out) : dpp_zero<DPP_ROW_SHR1>(b_out);
+                if (KEEP) {
+                    em = em_rot[r & 1] = dpp_keep<DPP_ROW_SHR1>(em_rot[r & 1], m_out);
+                    eb = eb_rot[r & 1] = dpp_keep<DPP_ROW_SHR1>(eb_rot[r & 1], b_out);
+                } else {
+                    em = EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, m_out) : dpp_zero<DPP_ROW_SHR1>(m_out);
+                    eb = EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, b_out) : dpp_zero<DPP_ROW_SHR1>(b_out);
+                }
             } else {
                 const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
-                const uint32_t u1 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lm, m_out) : dpp_zero<DPP_WAVE_SHR1>(m_out);
-                const uint32_t u2 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lb, b_out) : dpp_zero<DPP_WAVE_SHR1>(b_out);
+                uint32_t u1, u2;
+                if (KEEP) {
+                    u1 = em_rot[r & 1] = dpp_keep<DPP_WAVE_SHR1>(em_rot[r & 1], m_out);
+                    u2 = eb_rot[r & 1] = dpp_keep<DPP_WAVE_SHR1>(eb_rot[r & 1], b_out);
+                } else {
+                    u1 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lm, m_out) : dpp_zero<DPP_WAVE_SHR1>(m_out);
+                    u2 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lb, b_out) : dpp_zero<DPP_WAVE_SHR1>(b_out);
+                }
                 if (Gs == 32) { // lane 32 starts a group too
                     tok = leader ? fresh : u0;
                     em = leader ? lm : u1;
@@ -1121,10 +1153,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     const uint32_t fw = fm & (((tok >> 19) & 1u) - 1u);
                     if (__builtin_amdgcn_ballot_w64(fw != 0u) != 0ull) cells.wipe(fw);
                 } else if (F16) {
-                    // (65504 clears every finite state; a lane that reached +inf is wiped by hand)
-                    const uint32_t fi = fm & cells.best_is_inf();
+                    // (two rows at 65504 clear any state below 32768; a lane that got beyond is wiped by hand)
+                    const uint32_t fi = fm & cells.best_is_huge();
                     if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) cells.wipe(fi);
-                    cells.best &= ~fm;
+                    cells.best = (cells.best & ~fm) | (Z & fm);
                     go_v = (go_v & ~fm) | (SWG_F16_BIG & fm);
                     ge_v = (ge_v & ~fm) | (SWG_F16_BIG & fm);
                 } else {
@@ -1144,7 +1176,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 }
             }
             const uint2 e = cells.template row<(SWG_DYN_FENCE_ABOVE < K)>(prof_addr<0>(base, tok), prof_addr<1>(base, tok),
-                                                                           em, eb, go_v, ge_v);
+                                                                           em, eb, go_v, ge_v, zero_v);
             if (special) {
                 if (!WIDE) {
                     go_v = p.go;
@@ -1155,14 +1187,15 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     // is the last of the group to get here and finishes the pair
                     uint32_t *st = record();
                     const uint32_t at = nlast & (SWG_DYN_RING - 1u);
-                    const uint32_t c = cells.best ^ Z;
-                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, c & 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, c >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t c = cells.best ^ (F16 ? 0u : Z);
+                    const uint32_t cx = F16 ? f16_key(c & 0xFFFFu) : c & 0xFFFFu, cy = F16 ? f16_key(c >> 16) : c >> 16;
+                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (tail) {
                         const uint32_t pr = st[SWG_DYN_RING + at];
                         uint32_t sx = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         uint32_t sy = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at + 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (F16) { // (non-negative f16 values order like their bit patterns: the LDS maximum was taken on those)
+                        if (F16) { // (the LDS maximum was taken on order-preserving keys)
                             sx = (uint32_t)f16_score(sx);
                             sy = (uint32_t)f16_score(sy);
                         }
@@ -1587,6 +1620,55 @@ __global__ void swg_build_tokens_kernel(const uint32_t *codes, const uint64_t *c
     const uint32_t last = lx + 1u; // row of X's last residue
     if (last / 4u == k) t[last & 3u] |= SWG_TOK_LAST;
     tok[b] = make_uint4(t[0], t[1], t[2], t[3]);
+}
+
+// The same image from reference-shaped 16-lane batches (swg_fill_batches16): the two sequences of a pair are two
+// adjacent lanes of one batch, so a row's two residues are two adjacent bytes of the batch as the caller holds it.
+__global__ void swg_build_tokens16_kernel(const uint8_t *stage, const uint64_t *pair_src, const uint32_t *pair_len,
+                                          const uint32_t *pair_off, uint32_t n_pairs, uint4 *tok, uint32_t *bad)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_pairs == 0u || b >= (uint64_t)pair_off[n_pairs]) return;
+    uint32_t lo = 0u, hi = n_pairs; // pair_off[lo] <= b < pair_off[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if ((uint64_t)pair_off[mid] <= b) lo = mid; else hi = mid;
+    }
+    const uint32_t k = (uint32_t)(b - pair_off[lo]);
+    const uint64_t src = pair_src[lo] & ~(1ull << 63);
+    const bool has_y = (pair_src[lo] >> 63) == 0ull;
+    const uint32_t len = pair_len[lo];
+    uint32_t t[4];
+    bool wrong = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t row = 4u * k + (uint32_t)r; // rows 0, 1: reset rows; row r: residue r - 2
+        t[r] = 0u;
+        if (row >= 2u && row - 2u < len) {
+            const uint8_t *q = stage + src + (uint64_t)(row - 2u) * 16u;
+            const uint32_t x = q[0], y = has_y ? q[1] : 0u;
+            wrong |= x < 1u || x > 31u || (has_y && (y < 1u || y > 31u));
+            t[r] = ((x & 31u) << 3) | ((y & 31u) << 11);
+        }
+    }
+    if (wrong) atomicOr(bad, 1u);
+    if (k == 0u) {
+        t[0] |= SWG_TOK_RESET;
+        t[1] |= SWG_TOK_RESET | SWG_TOK_RESET2;
+    }
+    const uint32_t last = len + 1u;
+    if (last / 4u == k) t[last & 3u] |= SWG_TOK_LAST;
+    tok[b] = make_uint4(t[0], t[1], t[2], t[3]);
+}
+
+hipError_t swg_launch_build_tokens16(const uint8_t *d_stage, const uint64_t *d_pair_src, const uint32_t *d_pair_len,
+                                     const uint32_t *d_pair_off, uint32_t n_pairs, uint64_t total_blocks, uint4 *d_tok,
+                                     uint32_t *d_bad, hipStream_t stream)
+{
+    if (n_pairs == 0 || total_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_build_tokens16_kernel, dim3((uint32_t)((total_blocks + 255) / 256)), dim3(256), 0, stream, d_stage,
+                       d_pair_src, d_pair_len, d_pair_off, n_pairs, d_tok, d_bad);
+    return hipGetLastError();
 }
 
 // Bin image (systolic engine, bin-based int32 kernel): one workgroup per bin, thread s = slot s of

@@ -48,7 +48,7 @@ def main(budget=300.0, seed=1):
         ctx.set_scoring(sc, go, ge); ctx.set_query(q)
         for k in ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups", "segment_blocks"):
             ctx.set_option(k, 0)
-        for k in ("work_queue", "wide16", "autotune", "side_readout"):
+        for k in ("work_queue", "wide16", "autotune", "side_readout", "f16"):
             ctx.set_option(k, 1)
         ctx.set_option("long_helps", 0)
         opts = {}
@@ -63,7 +63,11 @@ def main(budget=300.0, seed=1):
             opts = {"long_split": int(rng.choice([-1, 100, 500, 2000]))}
         elif r < 0.6:
             opts = {"force_bits": 32}
+        elif r < 0.7:   # the int32 work-queue kernel at a forced geometry (round 3: these two families used to be exclusive)
+            opts = {"force_bits": 32, "cols_per_wave": int(rng.choice(ks)), "group_lanes": int(rng.choice([16, 32, 64]))}
+            if rng.random() < 0.5: opts["max_waves"] = 4
         if rng.random() < 0.2: opts["long_helps"] = 1
+        if rng.random() < 0.3: opts["f16"] = int(rng.choice([0, 2]))   # int16 cells only / f16 cells whatever the score bound
         if rng.random() < 0.2: opts["autotune"] = 0
         if rng.random() < 0.15: opts["wide16"] = 0
         if rng.random() < 0.25:   # multi-pass launches cut into segments of consecutive pairs (never shorter than a pair)

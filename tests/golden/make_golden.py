@@ -135,13 +135,14 @@ def mutated_prefix(rng, q, length, rate):
 
 
 def f16_boundary_cases():
-    """Round 3: databases of close relatives of the query whose scores straddle 2048 -- the ceiling of the packed-f16
-    cells (exact integers up to 2048), above which a sequence is flagged and re-scored in int32.  Batches of 16
-    records, the first the longest, as the reference's packer requires."""
+    """Round 3: databases of close relatives of the query whose scores straddle 4096 -- the ceiling of the packed-f16
+    cells (a score v is held as v - 2048, and f16 holds the integers of [-2048, 2048] exactly), from which on a
+    sequence is flagged and re-scored in int32.  Batches of 16 records, the first the longest, as the reference's
+    packer requires."""
     rng = np.random.default_rng(20261005)
     b62, pam = load_matrix("BLOSUM62"), load_matrix("PAM250")
-    for name, sub, go, ge, lq in (("blosum62_f16_boundary", b62, -2, -1, 600), ("blosum62_f16_boundary_gap11", b62, -11, -1, 640),
-                                  ("pam250_f16_boundary", pam, -2, -1, 520)):
+    for name, sub, go, ge, lq in (("blosum62_f16_boundary", b62, -2, -1, 1150), ("blosum62_f16_boundary_gap11", b62, -11, -1, 1230),
+                                  ("pam250_f16_boundary", pam, -2, -1, 1040)):
         q = rand_seq(rng, lq)
         seqs = []
         for b in range(6):

@@ -38,7 +38,7 @@ def _truth(g):
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_through_search(swg, ctx, name, engine, cells):
     """cells: which cells the diagonal engine's 16-bit fill runs on -- the library's choice, packed int16 only
-    (option f16 = 0), or the packed-f16 cells whenever the gap scores allow (f16 = 2: exact below 2048, every
+    (option f16 = 0), or the packed-f16 cells whenever the gap scores allow (f16 = 2: exact below 4096, every
     sequence that reaches it flagged and re-scored in int32; the *_f16_boundary fixtures straddle that ceiling)."""
     if engine == 1 and cells != "auto":
         pytest.skip("the systolic engine has int16 cells only")
@@ -54,7 +54,7 @@ def test_golden_through_search(swg, ctx, name, engine, cells):
     if cells == "int16" or engine == 1 or not gaps_ok:
         assert st["cell_form"] in (0, 1)
     elif cells == "f16":
-        assert st["cell_form"] == 2 and st["n_rescored"] == int((_truth(g) >= 2048).sum()), st
+        assert st["cell_form"] == 2 and st["n_rescored"] == int((_truth(g) >= 4096).sum()), st
     if g["ref_valid"][0]:
         assert np.array_equal(scores, g["ref16"].astype(np.int32))
     best = sorted(((-int(s), i) for i, s in enumerate(_truth(g))))[:10]
@@ -137,6 +137,36 @@ def test_diagonal_geometry_does_not_change_scores(swg, ctx, cols, group, waves):
         assert (st["engine"], st["cols_per_wave"], st["group_lanes"], st["waves"]) == (2, cols, group, waves)
         assert st["passes"] == -(-len(g["query"]) // (cols * group))
         db.close()
+
+
+@pytest.mark.parametrize("cols,group,waves", [(24, 16, 16), (12, 32, 16), (8, 64, 16), (12, 64, 8), (16, 16, 4),
+                                              (32, 64, 12), (8, 16, 4), (8, 32, 8), (6, 64, 16), (10, 32, 8), (6, 16, 4),
+                                              (20, 16, 4), (28, 16, 4), (14, 16, 4), (18, 32, 8), (22, 16, 4), (4, 64, 4),
+                                              (2, 64, 4), (2, 16, 4), (23, 16, 4), (21, 32, 8), (9, 64, 4), (31, 16, 4),
+                                              (25, 32, 4), (7, 16, 4), (13, 64, 8), (17, 16, 16), (3, 64, 4), (5, 32, 4),
+                                              (26, 16, 4), (30, 32, 4), (12, 32, 0), (23, 16, 0)])
+def test_q32_geometry_does_not_change_scores(swg, ctx, cols, group, waves):
+    """force_bits = 32 together with a forced lane-group geometry: swg_diag32q_kernel at every K and group width,
+    one pass and several (its form with edges), two classes and one, whole multi-pass launches cut into
+    segments.  A geometry whose int32 profile does not fit LDS is replaced by the library (fewest lanes that
+    do); the scores do not depend on which one ran.  (Round 2 only ever ran this kernel at the planner's pick.)"""
+    for name in ("blosum62_lq367", "blosum62_lq3000", "pam250_overflow_w", "blosum62_f16_boundary", "blosum62_tiny_db"):
+        g = load_golden(name)
+        _setup(ctx, g)
+        ctx.set_option("engine", 2)
+        ctx.set_option("force_bits", 32)
+        ctx.set_option("cols_per_wave", cols)
+        ctx.set_option("group_lanes", group)
+        ctx.set_option("max_waves", waves)
+        if (cols + group) % 3 == 0:
+            ctx.set_option("segment_blocks", (int(np.diff(g["offsets"]).max()) + 5) // 4 * 2 + 1)
+        db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+        scores, hits, st = ctx.search(db, k=5)
+        assert np.array_equal(scores, g["oracle32"]), (name, cols, group, waves, st)
+        assert st["path_bits"] == 32 and st["engine"] == 2 and st["work_queue"] == 1
+        assert st["passes"] >= -(-len(g["query"]) // (st["cols_per_wave"] * st["group_lanes"]))
+        db.close()
+    _reset_options(ctx)
 
 
 @pytest.mark.parametrize("cols,maxw", [(32, 0), (16, 0), (48, 0), (24, 0), (32, 1), (32, 2), (16, 3), (32, 5), (24, 2)])
@@ -292,7 +322,7 @@ def test_wide16_range_and_beyond(swg, ctx, orc, geom, f16):
     above 65535 (flagged by the wide form, re-scored in int32): a tryptophan-rich query (17 per
     match in PAM250) against copies of its prefixes, short decoys, and a one-pass geometry.
     f16 = 2 forces the packed-f16 cells on it: the copies' cells run past 65504 into +inf there, which must
-    neither reach the pairs that follow them in their lane groups nor change any score (everything from 2048
+    neither reach the pairs that follow them in their lane groups nor change any score (everything from 4096
     up is re-scored in int32)."""
     sc = swg.load_scoring("PAM250")
     rng = np.random.default_rng(33)
@@ -316,7 +346,7 @@ def test_wide16_range_and_beyond(swg, ctx, orc, geom, f16):
     got, hits, st = ctx.search(db, k=10)
     assert np.array_equal(got, want), (geom, st)
     assert st["cell_form"] == (2 if f16 == 2 else 1)
-    assert st["n_rescored"] == int((want >= (2048 if f16 == 2 else 65535)).sum()) and st["engine"] == 2
+    assert st["n_rescored"] == int((want >= (4096 if f16 == 2 else 65535)).sum()) and st["engine"] == 2
     assert hits == orc.topk(want, 10)
     db.close()
     _reset_options(ctx)
@@ -492,7 +522,7 @@ def test_full_size_databases_equal_the_reference_itself(swg, ctx, orc, cfg):
     _reset_options(ctx)
     db = swg.Database(flat, off).upload(ctx)
     scores, _, st = ctx.search(db)
-    # (f16 cells: exact below 2048, the few sequences that reach it are re-scored)
+    # (f16 cells: exact below 4096, the few sequences that reach it are re-scored)
     assert st["engine"] == 2 and st["path_bits"] == 16 and (st["n_rescored"] == 0 or cfg == "config5" or st["cell_form"] == 2)
     if cfg == "config5":
         # the same search on the path the configuration is named after: plain int16 (sticks at 32767), every
@@ -831,7 +861,7 @@ def test_config4_whole_database_on_one_gpu(swg, ctx, orc):
     ctx.set_option("autotune", 1)
     db.close()
     assert st["path_bits"] == 16 and st["cells"] == lq * int(off[-1])
-    assert st["n_rescored"] == (int((scores >= 2048).sum()) if st["cell_form"] == 2 else 0)
+    assert st["n_rescored"] == (int((scores >= 4096).sum()) if st["cell_form"] == 2 else 0)
     # top-100: consistent with the score vector, and every candidate's score equal to the oracle's
     order = np.lexsort((np.arange(n), -scores.astype(np.int64)))[:100]
     assert hits == [(int(scores[i]), int(i)) for i in order]
