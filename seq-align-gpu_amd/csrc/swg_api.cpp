@@ -112,7 +112,7 @@ extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
             for (auto &ev : sl.ev) HIP_TRY(ctx, hipEventCreate(&ev));
             HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
             HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_cand), SWG_TOPK_CAND_CAP * 8, hipHostMallocDefault));
-            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_counters), 64, hipHostMallocDefault));
+            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_counters), 128, hipHostMallocDefault));
         }
         ctx->cur = &ctx->slots[0];
         HIP_TRY(ctx, hipMalloc(&ctx->d_sub, 32 * 32));
@@ -140,6 +140,8 @@ extern "C" void swg_destroy(swg_ctx *ctx)
     (void)hipFree(ctx->d_profile[3]);
     (void)hipFree(ctx->d_profile[4]);
     (void)hipFree(ctx->d_profile[5]);
+    (void)hipFree(ctx->d_profile[6]);
+    (void)hipFree(ctx->d_profile[7]);
     (void)hipFree(ctx->d_scratch);
     for (SwgSlot &sl : ctx->slots) {
         for (auto &ev : sl.ev)
@@ -342,7 +344,7 @@ static int select_bufs(swg_ctx *ctx, swg_db *db, int slot)
     const size_t ns = (size_t)db->n_bins * SWG_BIN;
     if (!b.d_scores) {
         HIP_TRY(ctx, hipMalloc(&b.d_scores, std::max<size_t>(4, ns * 4)));
-        HIP_TRY(ctx, hipMalloc(&b.d_list, std::max<size_t>(4, ns * 4)));
+        HIP_TRY(ctx, hipMalloc(&b.d_list, std::max<size_t>(4, ns * 8)));
         HIP_TRY(ctx, hipMalloc(&b.d_counters, SWG_COUNTER_BYTES));
         HIP_TRY(ctx, hipMalloc(&b.d_keys, SWG_TOPK_CAND_CAP * 8));
         HIP_TRY(ctx, hipMalloc(&b.d_hist, 4096 * 4));
@@ -1151,6 +1153,123 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
     return SWG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// the pairs the f16 cells flagged, again on int16 cells
+// ---------------------------------------------------------------------------
+// A pair whose f16 score reached 4096 is run again by the same work-queue kernel on the packed int16 cells (or
+// the wide form when the query can score beyond 32767), which are exact where the f16 cells are not: 10
+// instead of 8.5 instructions per column pair, against 16 for the int32 kernel, and -- unlike the int32
+// kernel's 32-bit edge indices -- on databases of any size.  The launch reads the list's length on the device
+// and leaves at once when it is empty.  Geometry: few pairs get 64 lanes each (the shortest chain per row),
+// many the main fill's own.
+static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess, const SwgDiagPlan &main_plan, SwgDiagPlan *out)
+{
+    if (n_pairs_guess > 4u * (uint32_t)ctx->n_cu) {
+        *out = main_plan;
+        out->f16 = 0;
+        return true;
+    }
+    const int G = 64;
+    int best = -1, bestK = 0;
+    for (int v = 0; v < swg_num_diag_variants(); ++v) { // the most columns per pass that fit LDS
+        const int K = swg_diag_variant_info(v).K;
+        if (K > bestK && swg_diag_dyn_lds_bytes(K, G, 4) <= 160 * 1024) best = v, bestK = K;
+    }
+    if (best < 0) return false;
+    const size_t npass = (lq + (size_t)G * bestK - 1) / ((size_t)G * bestK);
+    for (int v = 0; v < swg_num_diag_variants(); ++v) { // the fewest columns per lane that need no more passes
+        const int K = swg_diag_variant_info(v).K;
+        if (K < bestK && (size_t)G * K * npass >= lq) best = v, bestK = K;
+    }
+    *out = SwgDiagPlan();
+    out->variant = best;
+    out->K = bestK;
+    out->G = G;
+    out->W = 4;
+    out->npass = (int)npass;
+    return true;
+}
+
+static int launch_dyn_list(swg_ctx *ctx, swg_db *db, const SwgDiagPlan &pl, bool wide, int go, int ge, const uint32_t *d_list,
+                           const uint32_t *d_count, hipStream_t s)
+{
+    SwgPairTokens &T = db->ptok;
+    const int form = wide ? 1 : 0;
+    const bool edges = pl.npass > 1 || form == 1;
+    if (pl.npass > 1 && (!T.d_edge[0] || T.edge_blocks < T.total_blocks)) {
+        (void)hipFree(T.d_edge[0]);
+        (void)hipFree(T.d_edge[1]);
+        T.d_edge[0] = T.d_edge[1] = nullptr;
+        const size_t bytes = std::max<size_t>(8, (size_t)T.total_blocks * 4 * sizeof(uint2));
+        HIP_TRY(ctx, hipMalloc(&T.d_edge[0], bytes));
+        HIP_TRY(ctx, hipMalloc(&T.d_edge[1], bytes));
+        T.edge_blocks = T.total_blocks;
+    }
+    const int kp = swg_diag_padded_cols(pl.K);
+    const uint32_t ncols = (uint32_t)(pl.npass * pl.G * kp);
+    int rc = ensure_profile_cols(ctx, 6, ncols, 2, (1ull << 52) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols, pl.K, kp,
+                                 4, SWG_LDS_SWIZZLE ? pl.G : 0, 0);
+    if (rc != SWG_OK) return rc;
+    const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
+    SwgDiagDynParams q;
+    memset(&q, 0, sizeof q);
+    q.tok = T.d_tok;
+    q.zero_block = (uint32_t)T.total_blocks;
+    q.pair_off = T.d_pair_off;
+    q.list = d_list;
+    q.list_count = d_count;
+    q.queue = db->d_counters + SWG_QUEUE_WORD(0);
+    q.scores = db->d_scores;
+    q.pair_limit = (uint32_t)(((size_t)db->n_bins * SWG_BIN) / 2);
+    q.G = (uint32_t)pl.G;
+    q.go = g | (g << 16);
+    q.ge = e | (e << 16);
+    q.prio_blocks = 0xFFFFFFFFu;
+    q.prio_blocks2 = 0xFFFFFFFFu;
+    q.turn_levels = 4u;
+    q.simd_ranks = db->d_counters + SWG_RANK_WORD(0);
+    const SwgKernelInfo info = swg_diag_variant_info(pl.variant);
+    const size_t lds = swg_diag_dyn_lds_bytes(pl.K, pl.G, pl.W);
+    const int per_cu = std::max(1, std::min<int>(info.max_waves / pl.W, (int)((160 * 1024) / lds)));
+    const int wgs = ctx->n_cu * std::min(per_cu, 3);
+    const uint32_t n_pairs = (uint32_t)swg_db_pair_count(db);
+    std::vector<std::pair<uint32_t, uint32_t>> segs;
+    if (!edges || T.total_blocks <= ctx->opt_seg_blocks) {
+        segs.push_back(std::make_pair(0u, n_pairs));
+        q.seg_origin = 0;
+        q.seg_blocks = (uint32_t)std::min<uint64_t>(T.total_blocks, ctx->opt_seg_blocks);
+    } else {
+        const std::vector<uint32_t> &pre = T.pair_blocks_prefix;
+        for (uint32_t b = 0; b < n_pairs;) {
+            const uint64_t limit = (uint64_t)pre[b] + ctx->opt_seg_blocks;
+            const uint32_t en = (uint32_t)(std::upper_bound(pre.begin() + b, pre.begin() + n_pairs + 1, limit,
+                                                            [](uint64_t v, uint32_t x) { return v < (uint64_t)x; }) - pre.begin()) - 1u;
+            if (en <= b) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "a pair of sequences too long for the multi-pass fill");
+            segs.push_back(std::make_pair(b, en));
+            b = en;
+        }
+    }
+    const size_t slice = (size_t)pl.G * kp * 64;
+    bool first_launch = true;
+    for (int pass = 0; pass < pl.npass; ++pass) {
+        q.profile = ctx->d_profile[6] + (size_t)pass * slice;
+        q.edge_in = pass > 0 ? T.d_edge[(pass - 1) & 1] : nullptr;
+        q.edge_out = pass + 1 < pl.npass ? T.d_edge[pass & 1] : nullptr;
+        for (const std::pair<uint32_t, uint32_t> &sg : segs) {
+            if (!first_launch) HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, s));
+            first_launch = false;
+            q.q_begin = sg.first;
+            q.q_end = sg.second;
+            if (segs.size() > 1) {
+                q.seg_origin = T.pair_blocks_prefix[sg.first];
+                q.seg_blocks = T.pair_blocks_prefix[sg.second] - q.seg_origin;
+            }
+            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, form, pl.W, wgs, q, s));
+        }
+    }
+    return SWG_OK;
+}
+
 // First search of a query length on a database: the cost model ranks the geometries, the few
 // best are timed once on this device (each is a complete, valid fill) and the fastest is kept.
 static int autotune_diag(swg_ctx *ctx, swg_db *db, size_t lq, int go, int ge, SwgTuned *tuned, int form)
@@ -1455,13 +1574,16 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // the f16 cells: every class on the work queue, and a re-score path for what they flag
     bool use_f16 = want_f16 && use_diag;
     for (int c = 0; use_f16 && c < wk.n_classes; ++c) use_f16 = diag_class_is_dynamic(ctx, db, wk.plan[c]);
-    if (q32_ok && (bits == 32 || score_bound >= (use_f16 ? 4096ull : wide ? 65535ull : 32767ull))) {
+    if (q32_ok && (bits == 32 || score_bound >= (wide ? 65535ull : 32767ull))) {
         if ((rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
         SwgDiagWork probe;
         q32_ok = db->ptok.ok && q32_list_plan(ctx, lq, 1, &probe) &&
                  (probe.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28)); // (32-bit edge indices)
     }
-    if (use_f16 && score_bound >= 4096ull && !q32_ok) use_f16 = false;
+    // what the f16 cells flag is run again on int16 cells (the wide form if scores may pass 32767); only what
+    // saturates those too needs the int32 kernel
+    const bool rerun_wide = use_f16 && score_bound >= 32767ull && ctx->opt_wide != 0;
+    if (use_f16 && score_bound >= (rerun_wide ? 65535ull : 32767ull) && !q32_ok) use_f16 = false;
     for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].f16 = use_f16 ? 1 : 0;
     const int32_t ceiling = use_f16 ? 4096 : wide ? 65535 : 32767;
     const SwgDiagPlan &dpl = wk.plan[0];
@@ -1509,7 +1631,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             }
         }
     }
-    const bool bin32 = use_diag32 && ((bits == 32 && !use_q32) || (may_saturate && !q32_ok)); // the bin-based int32 kernel is needed
+    const bool int32_level_planned = may_saturate && (!use_f16 || score_bound >= (rerun_wide ? 65535ull : 32767ull));
+    const bool bin32 = use_diag32 && ((bits == 32 && !use_q32) || (int32_level_planned && !q32_ok)); // the bin-based int32 kernel is needed
     if (bin32) {
         rc = ensure_profile_cols(ctx, 1, (uint32_t)(npass32 * 64 * SWG_DIAG32_K), 4, (1ull << 30) ^ (uint64_t)npass32);
         if (rc != SWG_OK) return rc;
@@ -1536,7 +1659,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
 
     // the systolic engine and the bin-based int32 kernel read the bin image (built on the device on first use)
-    if (((!use_diag && !use_q32) || (may_saturate && !q32_ok)) && (rc = ensure_bins(ctx, const_cast<swg_db *>(db))) != SWG_OK)
+    if (((!use_diag && !use_q32) || (int32_level_planned && !q32_ok)) && (rc = ensure_bins(ctx, const_cast<swg_db *>(db))) != SWG_OK)
         return rc;
 
     hipStream_t s = ctx->stream;
@@ -1590,13 +1713,29 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         HIP_TRY(ctx, swg_launch_fill(bits, main_pl.variant, main_pl.W, main_pl.workgroups, p, s));
     }
     if (!use_diag && !use_q32) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
-    if (may_saturate) {
-        // counters [1] = flagged sequences, [6] = their rows in units of 16 (what the f16 veto looks at)
-        HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, ceiling, db->d_list, db->d_counters + 1, db->d_lens,
-                                                  db->d_counters + 6, s));
+    int32_t level_ceiling = ceiling; // what the fill before the int32 level saturates at
+    bool int32_level = may_saturate;
+    uint32_t *seq_list = db->d_list;
+    if (may_saturate && use_f16) {
+        // counters [17] = flagged pairs (the list's length), [16] = flagged sequences, [6] = their rows / 16 (the veto's input)
+        HIP_TRY(ctx, swg_launch_collect_flagged_pairs(db->d_scores, (uint32_t)(n_slots / 2), ceiling, db->d_list, db->d_counters + 17,
+                                                      db->d_counters + 16, db->d_lens, db->d_counters + 6, s));
+        SwgDiagPlan lp;
+        const uint32_t guess = db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
+        if (!i16_list_plan(ctx, lq, guess, wk.plan[0], &lp)) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no geometry for the int16 re-run");
+        HIP_TRY(ctx, hipMemsetAsync(db->d_counters + SWG_QUEUE_WORD(0), 0, (size_t)(SWG_COUNTER_BYTES - SWG_QUEUE_WORD(0) * 4u), s));
+        if ((rc = launch_dyn_list(ctx, const_cast<swg_db *>(db), lp, rerun_wide, go, ge, db->d_list, db->d_counters + 17, s)) != SWG_OK) return rc;
+        level_ceiling = rerun_wide ? 65535 : 32767;
+        int32_level = score_bound >= (uint64_t)level_ceiling;
+        seq_list = db->d_list + n_slots; // (the pair list keeps the first half)
+    }
+    if (int32_level) {
+        // counters [1] = saturated sequences (the list's length), [6] = their rows in units of 16
+        HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, level_ceiling, seq_list, db->d_counters + 1,
+                                                  use_f16 ? nullptr : db->d_lens, db->d_counters + 6, s));
         p.profile = ctx->d_profile[1];
         p.queue = db->d_counters + 2;
-        p.list = db->d_list;
+        p.list = seq_list;
         p.list_count = db->d_counters + 1;
         p.n_items = 0;
         p.go = go;
@@ -1607,14 +1746,14 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         // search (it did until round 3: a round trip per search, and the end of the two-deep pipeline of
         // swg_search_begin).  Only its lane-group width is a guess -- few flagged sequences get 64 lanes each,
         // many the narrowest group that covers the query -- made from what the last search of this database saw.
-        const uint32_t guess = db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
+        const uint32_t guess = !use_f16 && db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
         if (use_diag32 && q32_ok && q32_list_plan(ctx, lq, guess, &wkl)) {
             // (fresh queue counters and rank table: the fill's are spent; no events of its own: the
             // re-score is timed as ev[2] .. ev[3] like the other re-score forms)
             HIP_TRY(ctx, hipMemsetAsync(db->d_counters + SWG_QUEUE_WORD(0), 0,
                                         (size_t)(SWG_COUNTER_BYTES - SWG_QUEUE_WORD(0) * 4u), s));
             bool two = false;
-            rc = launch_q32(ctx, db, wkl, go, ge, db->d_list, db->d_counters + 1, std::max<uint32_t>(2u * guess, 4096u),
+            rc = launch_q32(ctx, db, wkl, go, ge, seq_list, db->d_counters + 1, std::max<uint32_t>(2u * guess, 4096u),
                             db->d_counters + SWG_QUEUE_WORD(0), &two, false);
             if (rc != SWG_OK) return rc;
         } else if (use_diag32) {
@@ -1678,7 +1817,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         if ((rc = slot_scores(ctx, S, n_slots)) != SWG_OK) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(S->h_scores, db->d_scores, n_slots * 4, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(S->h_counters, db->d_counters, 64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(S->h_counters, db->d_counters, 128, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(S->ev_done, s));
     return SWG_OK;
 }
@@ -1733,13 +1872,13 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     st.total_ms = ms;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[3], ctx->cur->ev[4]));
     const double topk_dev_ms = ms;
-    st.n_rescored = h_counters[1];
+    st.n_rescored = S->used_f16 ? h_counters[16] : h_counters[1];
     st.path_bits = bits;
     st.cell_form = use_diag ? diag_class_form(ctx, db, dpl) : 0;
     if (may_saturate) {
         // what the next search's plan may assume (never its results)
         swg_db *mdb = const_cast<swg_db *>(db);
-        mdb->sat_hint = (long long)h_counters[1];
+        mdb->sat_hint = (long long)(S->used_f16 ? h_counters[17] : h_counters[1]); // (f16: pairs; else sequences)
         // f16 cells that flag more than 1/50 of the rows cost more in re-scores than they save
         if (S->used_f16 && (uint64_t)h_counters[6] * 16ull * 50ull > db->residues + 2ull * db->n_local) mdb->f16_veto_epoch = S->epoch;
     }

@@ -145,8 +145,9 @@ struct swg_db {
     // plain members below point at the set of the search being queued
     struct Bufs {
         int32_t *d_scores = nullptr;    // [n_bins*128] by sorted rank
-        uint32_t *d_list = nullptr;     // [n_bins*128] saturated ranks
-        uint32_t *d_counters = nullptr; // [0] work queue, [1] saturated count, [2] re-score queue, [3..5] top-K
+        uint32_t *d_list = nullptr;     // [2*n_bins*128]: flagged pairs of the f16 fill, then (second half) saturated ranks
+        uint32_t *d_counters = nullptr; // [0] work queue, [1] saturated count, [2] re-score queue, [3..5] top-K, [6] flagged rows / 16,
+                                        // [8..15] class stamps, [16] sequences the f16 fill flagged, [17] their pairs
         uint64_t *d_keys = nullptr;     // top-K candidate keys (SWG_TOPK_CAND_CAP)
         uint32_t *d_hist = nullptr;     // top-K score histogram
     } bufs[4];
@@ -178,7 +179,7 @@ struct SwgSlot {
     SwgDiagWork wk;
     swg_stats st;
     uint64_t *h_cand = nullptr;     // pinned, SWG_TOPK_CAND_CAP keys
-    uint32_t *h_counters = nullptr; // pinned, 8 words
+    uint32_t *h_counters = nullptr; // pinned, 32 words
     int32_t *h_scores = nullptr;    // pinned landing buffer of the score read-out, grown on demand
     size_t h_scores_cap = 0;        // entries
 };
@@ -225,9 +226,10 @@ struct swg_ctx {
     // [0] int16, whole 4-column chunks per lane; [1] int32 (bin-based kernels); [2] / [3] int16 in per-lane
     // slices padded to whole chunks, long class / bulk; [4] / [5] int32 in 2-column chunks (work-queue
     // int32 kernel), bulk or list / long class
-    uint8_t *d_profile[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t d_profile_cap[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t profile_tag[6] = {0, 0, 0, 0, 0, 0}; // identifies (query, scoring, geometry) currently built
+    // int32 kernel), bulk or list / long class; [6] int16, the re-run of the pairs the f16 cells flagged
+    uint8_t *d_profile[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t d_profile_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t profile_tag[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // identifies (query, scoring, geometry) currently built
     uint64_t epoch = 1;               // bumps whenever scoring or query change
     uint32_t *d_scratch = nullptr;
     size_t d_scratch_cap = 0; // dwords

@@ -69,6 +69,10 @@ struct SwgDiagDynParams {
     const uint32_t *pair_off; // [n_pairs+1] block offset of each pair's tokens
     uint32_t q_begin, q_end;  // this launch serves pairs [q_begin, q_end) ...
     uint32_t *queue;          // ... handed out by these SWG_DYN_SHARDS counters (zero before the launch)
+    // list mode (or null): the counters hand out positions 0 .. *list_count - 1 of `list`, whose entries are pair
+    // ids; an entry outside [q_begin, q_end) is skipped (it belongs to another segment's launch).  No second range.
+    const uint32_t *list;
+    const uint32_t *list_count;
     uint32_t q2_begin, q2_end; // then helps with [q2_begin, q2_end) (empty: none), which another
     uint32_t *queue2;          // launch is serving off these counters
     const uint8_t *profile;   // [G lanes][KP/4 chunks][32][4] int16
@@ -200,6 +204,9 @@ hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code
 // Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, 65535 in the wide form, 4096 for the
 // packed-f16 cells) to list.
 hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t stream);
+hipError_t swg_launch_collect_flagged_pairs(const int32_t *d_scores, uint32_t n_pairs, int32_t ceiling, uint32_t *d_list,
+                                            uint32_t *d_count, uint32_t *d_seqs, const uint32_t *d_lens, uint32_t *d_rows16,
+                                            hipStream_t stream);
 // d_lens / d_rows16 (or NULL): also adds up the flagged sequences' lengths, in units of 16 rows.
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling,
                                         uint32_t *d_list, uint32_t *d_count, const uint32_t *d_lens, uint32_t *d_rows16,

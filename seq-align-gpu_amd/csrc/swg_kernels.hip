@@ -908,6 +908,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         return reinterpret_cast<uint32_t *>(smem + slice) + (((uint32_t)w << (6 - gshift)) + (l >> gshift)) * SWG_DYN_STATE;
     };
+    // List mode (the re-run of the pairs the f16 cells flagged): the queue hands out positions of a device-side
+    // list of pair ids instead of the ids themselves; [q_begin, q_end) then only says which of them belong to this
+    // launch (a segment of a very large database).  An empty list -- the usual case -- ends the launch here.
+    const uint32_t n_list = p.list ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*p.list_count) : 0u;
+    if (p.list && n_list == 0u) return;
     const uint64_t t_start = p.trace ? wall_clock64() : 0ull;
     if (p.stamps && lane == 0) atomicMax(p.stamps, ~(unsigned long long)wall_clock64()); // earliest start, as the maximum of the complements (0 = not run)
     // several queries in one launch: row y of the grid works for query y (its profile, its queue, its scores)
@@ -1018,6 +1023,19 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     }
                     const uint32_t shard = (blockIdx.x + tried) & (SWG_DYN_SHARDS - 1u);
                     uint32_t *ctr = (second ? p.queue2 : queue) + shard * SWG_DYN_SHARD_STRIDE;
+                    if (p.list) {
+                        const uint32_t at = shard + SWG_DYN_SHARDS * atomicAdd(ctr, 1u);
+                        if (at < n_list) {
+                            const uint32_t cand = p.list[at];
+                            if (cand >= p.q_begin && cand < p.q_end) {
+                                nq = cand;
+                                break;
+                            }
+                            continue; // (another segment's pair: the same shard again)
+                        }
+                        ++tried;
+                        continue;
+                    }
                     const uint32_t cand = (second ? p.q2_begin : p.q_begin) + shard + SWG_DYN_SHARDS * atomicAdd(ctr, 1u);
                     if (cand < (second ? p.q2_end : p.q_end)) {
                         nq = cand;
@@ -2248,6 +2266,32 @@ hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hi
     if (na + nb == 0) return hipSuccess;
     hipLaunchKernelGGL(swg_zero2_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, stream, static_cast<uint4 *>(a), na,
                        static_cast<uint4 *>(b), nb);
+    return hipGetLastError();
+}
+
+// The same by pairs (ranks 2p, 2p+1 share a lane group of the 16-bit fill): pair p is listed once if either of its
+// sequences reached the ceiling; *seqs counts the flagged sequences, *rows16 the rows of the listed pairs in
+// units of 16.
+__global__ void swg_collect_flagged_pairs_kernel(const int32_t *scores, uint32_t n_pairs, int32_t ceiling, uint32_t *list,
+                                                 uint32_t *count, uint32_t *seqs, const uint32_t *lens, uint32_t *rows16)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t fx = scores[2u * p] >= ceiling, fy = scores[2u * p + 1u] >= ceiling;
+    if (fx | fy) {
+        list[atomicAdd(count, 1u)] = p;
+        atomicAdd(seqs, fx + fy);
+        atomicAdd(rows16, (lens[2u * p] + 17u) / 16u);
+    }
+}
+
+hipError_t swg_launch_collect_flagged_pairs(const int32_t *d_scores, uint32_t n_pairs, int32_t ceiling, uint32_t *d_list,
+                                            uint32_t *d_count, uint32_t *d_seqs, const uint32_t *d_lens, uint32_t *d_rows16,
+                                            hipStream_t stream)
+{
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_collect_flagged_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, d_scores, n_pairs,
+                       ceiling, d_list, d_count, d_seqs, d_lens, d_rows16);
     return hipGetLastError();
 }
 

@@ -352,6 +352,37 @@ def test_wide16_range_and_beyond(swg, ctx, orc, geom, f16):
     _reset_options(ctx)
 
 
+@pytest.mark.parametrize("lq,opts", [(1300, {}), (1300, {"segment_blocks": 700}), (2600, {"cols_per_wave": 16, "group_lanes": 16}),
+                                     (900, {"long_split": 300})])
+def test_f16_flagged_pairs_rerun_few_and_many(swg, ctx, orc, lq, opts):
+    """What the f16 cells flag (scores from 4096 up) is run again on the int16 cells by the same work-queue kernel
+    in list mode.  The re-run's geometry is a guess from the previous search of the database: 64 lanes per pair
+    for a few flagged pairs (the first search knows nothing: that plan), the main fill's own for many (the second
+    search, which has seen that more than a thousand pairs were flagged).  Both must give the oracle's scores;
+    multi-pass re-runs cut into segments and two-class main fills included."""
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(0xF16, lq)
+    flat, off, planted = swg.synth_db(0xF16, 4200, query=q, fraction=0.7, subst=0.08, max_len=900)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    n_flag = int((want >= 4096).sum())
+    assert (n_flag > 2200 or lq < 1000) and (want < 4096).sum() > 500, (n_flag, planted)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    ctx.set_option("f16", 2)       # (also past the veto: this database flags most of its rows)
+    ctx.set_option("autotune", 0)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    db = swg.Database(flat, off).upload(ctx)
+    for attempt in range(2):
+        got, hits, st = ctx.search(db, k=25)
+        assert np.array_equal(got, want), (attempt, opts, st)
+        assert st["cell_form"] == 2 and st["n_rescored"] == n_flag and hits == orc.topk(want, 25)
+    db.close()
+    _reset_options(ctx)
+    ctx.set_option("autotune", 1)
+
+
 @pytest.mark.parametrize("name", ["pam250_lq128", "blosum62_lq367", "blosum62_tiny_db", "blosum62_lq1",
                                   "pam250_overflow_w", "blosum62_lq3000"])
 def test_device_topk_matches_oracle_order(swg, ctx, orc, name):
