@@ -118,6 +118,8 @@ def parse_args():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     ap.add_argument("--f16", type=int, default=-1, help="experiment: 0 = int16 cells only, 2 = f16 cells whenever the gap scores allow")
     ap.add_argument("--wide16", type=int, default=-1, help="experiment: 0 = plain int16 cells + int32 re-score instead of the wide form")
+    ap.add_argument("--gapopen", type=int, default=-2, help="experiment: gap_open (the configurations use the reference's default -2)")
+    ap.add_argument("--gapextend", type=int, default=-1, help="experiment: gap_extend (default -1)")
     ap.add_argument("--spawn-dry-run", action="store_true",
                     help="--gpus N without a launcher: print the launch command as JSON instead of running it")
     return ap.parse_args()
@@ -166,7 +168,7 @@ class Env:
 def make_context(env, q, sc):
     a = env.args
     ctx = env.swg.Context(env.local_rank)
-    ctx.set_scoring(sc, -2, -1)
+    ctx.set_scoring(sc, a.gapopen, a.gapextend)
     ctx.set_query(q)
     ctx.set_option("cols_per_wave", a.cols)
     ctx.set_option("max_waves", a.max_waves)
@@ -318,10 +320,10 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
         step_fill_ms = float(np.mean(fill_ms))
         if sharded:
             workload = ("config %d: 1 query (%d aa) vs ONE %d-seq synthetic protein DB dealt by bins over %d GPU(s), "
-                        "%s, gaps -2/-1, global top-%d by one RCCL all-reduce" % (cnum, lq, n, env.world, cfg["matrix"], K))
+                        "%s, gaps %d/%d, global top-%d by one RCCL all-reduce" % (cnum, lq, n, env.world, cfg["matrix"], a.gapopen, a.gapextend, K))
         else:
-            workload = ("config %d: 1 query (%d aa) vs %d-seq synthetic protein DB%s, %s, gaps -2/-1, top-%d"
-                        % (cnum, lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], K))
+            workload = ("config %d: 1 query (%d aa) vs %d-seq synthetic protein DB%s, %s, gaps %d/%d, top-%d"
+                        % (cnum, lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], a.gapopen, a.gapextend, K))
             if cnum == 4 and not n_override:
                 workload += " (one GPU's eighth of the 10M-sequence database)"
             if cfg.get("similar"):
@@ -425,7 +427,8 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
         kname = ("swg_diag_dyn_kernel<K=%d,%s>" if last["work_queue"] else "swg_diag_kernel<K=%d,%s>") % (
             last["cols_per_wave"], {0: "int16", 1: "wide", 2: "f16"}[form])
     elif last["engine"] == 2 and last["work_queue"]:
-        ops_per_cell, kname = 8.0, "swg_diag32q_kernel<K=%d>" % last["cols_per_wave"]
+        exact = a.gapopen > 0 or a.gapextend > 0    # (gap scores the reduced algebra cannot express: the exact cells)
+        ops_per_cell, kname = (12.0 if exact else 8.0), "swg_diag32q_kernel<K=%d%s>" % (last["cols_per_wave"], ",exact" if exact else "")
     elif last["engine"] == 2:
         ops_per_cell, kname = 12.0, "swg_diag32_kernel"
     else:
@@ -471,7 +474,7 @@ def verify_topk(env, ctx, db, q, sc, flat, off, index, K, merger, timed_hits):
         sub_off[1:] = np.cumsum(lens)
         sub_flat = (np.concatenate([flat[int(off[p]):int(off[p + 1])] for p in positions])
                     if positions else np.zeros(0, np.int8))
-        return orc.score_db(q, sub_flat, sub_off, table, -2, -1)
+        return orc.score_db(q, sub_flat, sub_off, table, env.args.gapopen, env.args.gapextend)
 
     pos = [pos_of(g) for _, g in local]
     want = oracle_scores(pos)

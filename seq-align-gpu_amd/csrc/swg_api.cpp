@@ -313,6 +313,8 @@ void swg_db_release_device(swg_db *db)
     (void)hipFree(db->ptok.d_edge[1]);
     (void)hipFree(db->ptok.d_edge32[0]);
     (void)hipFree(db->ptok.d_edge32[1]);
+    (void)hipFree(db->ptok.d_edge32d[0]);
+    (void)hipFree(db->ptok.d_edge32d[1]);
     db->ptok = SwgPairTokens();
     for (SwgDiagLayout &L : db->diag) {
         (void)hipFree(L.d_tok);
@@ -1060,12 +1062,69 @@ static bool q32_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_items, SwgDi
     return true;
 }
 
+// Geometry of the exact int32 cells (gap scores of any sign) for a whole database: one class; the narrowest lane
+// group that covers the query in one pass with at most SWG_X32_MAX_K columns per lane (forced cols_per_wave /
+// group_lanes are honoured where they fit), else several passes of 64 lanes.
+static bool x32_plan(const swg_ctx *ctx, const swg_db *db, size_t lq, SwgDiagWork *wk)
+{
+    auto set = [&](int v, int K, int G, size_t npass) {
+        *wk = SwgDiagWork();
+        wk->n_classes = 1;
+        wk->plan[0].variant = v;
+        wk->plan[0].K = K;
+        wk->plan[0].G = G;
+        wk->plan[0].W = 4;
+        wk->plan[0].npass = (int)npass;
+        wk->pair_begin[0] = 0;
+        wk->pair_end[0] = swg_db_pair_count(db);
+    };
+    auto fits = [&](int K, int G) { return K <= SWG_X32_MAX_K && swg_diag32q_lds_bytes(K, G, 4) <= 160 * 1024; };
+    if (ctx->opt_cols > 0 && ctx->opt_group > 0) {
+        for (int v = 0; v < swg_num_diag_variants(); ++v) {
+            const int K = swg_diag_variant_info(v).K, G = (int)ctx->opt_group;
+            if (K != (int)ctx->opt_cols || !fits(K, G)) continue;
+            const size_t np = (lq + (size_t)G * K - 1) / ((size_t)G * K);
+            if (np > 64) continue;
+            set(v, K, G, np);
+            return true;
+        }
+    }
+    const int groups[3] = {16, 32, 64};
+    for (int gi = 0; gi < 3; ++gi) {
+        const int G = groups[gi];
+        int best = -1, bestK = 1 << 30;
+        for (int v = 0; v < swg_num_diag_variants(); ++v) {
+            const int K = swg_diag_variant_info(v).K;
+            if ((size_t)G * K >= lq && K < bestK && fits(K, G)) best = v, bestK = K;
+        }
+        if (best >= 0) {
+            set(best, bestK, G, 1);
+            return true;
+        }
+    }
+    const int G = 64;
+    int best = -1, bestK = 0;
+    for (int v = 0; v < swg_num_diag_variants(); ++v) {
+        const int K = swg_diag_variant_info(v).K;
+        if (K > bestK && fits(K, G)) best = v, bestK = K;
+    }
+    if (best < 0) return false;
+    const size_t npass = (lq + (size_t)G * bestK - 1) / ((size_t)G * bestK);
+    if (npass > 64) return false;
+    for (int v = 0; v < swg_num_diag_variants(); ++v) {
+        const int K = swg_diag_variant_info(v).K;
+        if (K < bestK && (size_t)G * K * npass >= lq) best = v, bestK = K;
+    }
+    set(best, bestK, G, npass);
+    return true;
+}
+
 // Launches the int32 work-queue fill: every sequence of the plan's classes (list == NULL), or the
 // device-side list of ranks with one class.  A plan of several passes (one class) is one launch per
 // pass, the rows' edges going from launch to launch through memory.  Events as launch_diag.
 static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int go, int ge, const uint32_t *d_list,
                       const uint32_t *d_list_count, uint32_t list_items, uint32_t *queue_words, bool *two_ends,
-                      bool timing_events = true)
+                      bool timing_events = true, bool exact = false)
 {
     hipStream_t s = ctx->stream;
     SwgPairTokens &T = const_cast<swg_db *>(db)->ptok;
@@ -1083,6 +1142,15 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
             HIP_TRY(ctx, hipMalloc(&T.d_edge32[0], bytes));
             HIP_TRY(ctx, hipMalloc(&T.d_edge32[1], bytes));
             T.edge32_blocks = T.total_blocks;
+        }
+        if (exact && (!T.d_edge32d[0] || T.edge32d_blocks < T.total_blocks)) { // the exact cells' third edge value
+            (void)hipFree(T.d_edge32d[0]);
+            (void)hipFree(T.d_edge32d[1]);
+            T.d_edge32d[0] = T.d_edge32d[1] = nullptr;
+            const size_t bytes = std::max<size_t>(8, (size_t)T.total_blocks * 4 * 2 * sizeof(int32_t));
+            HIP_TRY(ctx, hipMalloc(&T.d_edge32d[0], bytes));
+            HIP_TRY(ctx, hipMalloc(&T.d_edge32d[1], bytes));
+            T.edge32d_blocks = T.total_blocks;
         }
     }
     for (int c = 0; c < wk.n_classes; ++c) {
@@ -1119,8 +1187,8 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
         q.scores = db->d_scores;
         q.seq_limit = (uint32_t)n_slots;
         q.G = (uint32_t)pl.G;
-        q.go = -go;
-        q.ge = -ge;
+        q.go = exact ? go : -go; // (the exact cells add the signed scores, the reduced ones subtract magnitudes)
+        q.ge = exact ? ge : -ge;
         q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
         q.simd_ranks = db->d_counters + SWG_RANK_WORD(c);
         const int wgs = q32_class_workgroups(ctx, wk, c, items);
@@ -1140,7 +1208,9 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
             q.profile = ctx->d_profile[4 + c] + (size_t)pass * slice;
             q.edge_in = pass > 0 ? T.d_edge32[(pass - 1) & 1] : nullptr;
             q.edge_out = pass + 1 < pl.npass ? T.d_edge32[pass & 1] : nullptr;
-            HIP_TRY(ctx, swg_launch_diag32q(pl.variant, pl.npass > 1, W, wgs, q, qs));
+            q.edge_d_in = exact && pass > 0 ? T.d_edge32d[(pass - 1) & 1] : nullptr;
+            q.edge_d_out = exact && pass + 1 < pl.npass ? T.d_edge32d[pass & 1] : nullptr;
+            HIP_TRY(ctx, swg_launch_diag32q(pl.variant, pl.npass > 1, exact, W, wgs, q, qs));
         }
     }
     if (wk.n_classes == 2) {
@@ -1597,7 +1667,21 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
     const int npass32 = (int)((lq + 64 * SWG_DIAG32_K - 1) / (64 * SWG_DIAG32_K));
     SwgDiagWork wk32;
-    bool use_q32 = false;
+    bool use_q32 = false, exact32 = false;
+    if (bits == 32 && !fast_ok && use_diag32 && ctx->opt_dynamic != 0) {
+        // gap scores the reduced algebra cannot express (a positive one): the same work-queue kernel on the
+        // exact cells, unless the token array is beyond its 32-bit edge indices
+        if ((rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db))) != SWG_OK) return rc;
+        if (db->ptok.ok) {
+            // the planner's split into a bulk and a long class where it fits the int32 profile and the exact cells'
+            // register budget (config 2's shape: 2 580 GCUPS as one class, the longest pairs' chains last), else one class
+            bool two = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves, ctx->opt_long_split,
+                                          ctx->opt_workgroups == 0, true, &wk32) > 0 && q32_plan_fits(wk32, lq);
+            for (int c = 0; two && c < wk32.n_classes; ++c) two = wk32.plan[c].K <= SWG_X32_MAX_K;
+            if (two || (x32_plan(ctx, db, lq, &wk32) && (wk32.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28))))
+                use_q32 = exact32 = true;
+        }
+    }
     if (bits == 32 && q32_ok) {
         use_q32 = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves, ctx->opt_long_split,
                                      ctx->opt_workgroups == 0, true, &wk32) > 0 && q32_plan_fits(wk32, lq);
@@ -1681,7 +1765,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     if (use_diag) {
         if ((rc = launch_diag(ctx, db, wk, go, ge, &two_ends)) != SWG_OK) return rc;
     } else if (use_q32) {
-        if ((rc = launch_q32(ctx, db, wk32, go, ge, nullptr, nullptr, 0, db->d_counters + SWG_QUEUE_WORD(0), &two_ends)) != SWG_OK)
+        if ((rc = launch_q32(ctx, db, wk32, go, ge, nullptr, nullptr, 0, db->d_counters + SWG_QUEUE_WORD(0), &two_ends, true, exact32)) != SWG_OK)
             return rc;
     } else if (bits == 32 && use_diag32) {
         p.profile = ctx->d_profile[1];

@@ -68,7 +68,8 @@ struct SwgPairTokens {
     uint32_t *d_pair_off = nullptr;
     uint2 *d_edge[2] = {nullptr, nullptr};    // multi-pass: (M,B) per row between consecutive passes, ping-pong
     int2 *d_edge32[2] = {nullptr, nullptr};   // the same for the int32 work-queue kernel: per row and per sequence of the pair
-    uint64_t edge_blocks = 0, edge32_blocks = 0; // token blocks the edge buffers were allocated for (a re-filled database may have grown)
+    int32_t *d_edge32d[2] = {nullptr, nullptr}; // ... and the third edge value of its exact cells (gap scores of any sign)
+    uint64_t edge_blocks = 0, edge32_blocks = 0, edge32d_blocks = 0; // token blocks the edge buffers were allocated for (a re-filled database may have grown)
     std::vector<uint32_t> pair_blocks_prefix; // host copy of pair_off
 };
 

@@ -123,11 +123,19 @@ struct SwgDiagQ32Params {
     // for the next (null: last); index = 2 * (row's position in the pair-major token order) + (X or Y)
     const int2 *edge_in;
     int2 *edge_out;
+    // the exact cells (gap scores of any sign; go / ge are then the SIGNED scores gap_open + gap_extend, gap_extend):
+    // their third edge value, D = max(H, A, B), same index
+    const int32_t *edge_d_in;
+    int32_t *edge_d_out;
 };
 int swg_q32_padded_cols(int K);
 size_t swg_diag32q_lds_bytes(int K, int G, int W);
 // variant: index into the diagonal variants (swg_diag_variant_info gives its K)
-hipError_t swg_launch_diag32q(int variant, bool edges, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream);
+#define SWG_X32_WAVES_ABOVE16 12 // wavefronts per CU the exact int32 cells are compiled for when K > 16
+#define SWG_X32_MAX_K 28         // ... and the most columns per lane they hold without spilling
+// exact: the reference's recurrence term by term (12 instructions per cell, gap scores of any sign) instead of the
+// reduced algebra (8 per cell, non-positive gap scores)
+hipError_t swg_launch_diag32q(int variant, bool edges, bool exact, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream);
 
 struct SwgKernelInfo {
     int bits;      // 16 or 32

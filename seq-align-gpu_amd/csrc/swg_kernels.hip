@@ -1322,13 +1322,69 @@ template <int K> struct CellsQ32 {
     }
 };
 
+// The reference's recurrence term by term (src/alignment.c:124-161), for gap scores of any sign (the reduced algebra
+// above needs gap_open <= 0 and gap_extend <= 0; the reference's CLI accepts positive ones,
+// src/alignment_cmdline.c:255-267): per column U = max(H, B), A, D = max(H, A, B) of the previous row; a lane's
+// right edge is (L = max(H, A), B, D).  12 instructions per cell.  go / ge are the signed scores; on a reset row
+// they are -2^29, which zeroes every state in one row.
+template <int K> struct CellsX32 {
+    static constexpr int KP = (K + 1) / 2 * 2;
+    static constexpr int CHUNK = 32 * 2 * 4;
+    int U[K], A[K], D[K];
+    int best, ddl;
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) U[k] = A[k] = D[k] = 0;
+        best = 0;
+        ddl = 0;
+    }
+
+    // el / eb / ed: L, B and D of the column left of this lane's strip in this row (ed becomes the next row's diagonal)
+    template <bool FENCED = false> DEVINL int2 row(uint32_t ax, int el, int eb, int ed, int go, int ge, int &od)
+    {
+        constexpr int NCH = KP / 2;
+        int dd = ddl;
+        int ll = el, bl = eb;
+        int2 nx = lds_read_i2(ax);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int2 w = nx;
+            if (c + 1 < NCH) nx = lds_read_i2(ax + (c + 1) * CHUNK);
+            const int s[2] = {w.x, w.y};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 2 * c + u;
+                if (k >= K) break;
+                const int h = imax(dd + s[u], 0);             // src/alignment.c:124-129
+                const int a = imax3(U[k] + go, A[k] + ge, 0); // src/alignment.c:142-147
+                const int b = imax3(ll + go, bl + ge, 0);     // src/alignment.c:156-161
+                dd = D[k];
+                U[k] = imax(h, b);
+                ll = imax(h, a);
+                D[k] = imax(ll, b);
+                A[k] = a;
+                bl = b;
+                best = imax(best, h);                         // src/alignment.c:133
+            }
+            if (FENCED && (c & 1) && c + 1 < NCH) __builtin_amdgcn_sched_barrier(0);
+        }
+        ddl = ed;
+        od = D[K - 1];
+        return make_int2(ll, bl);
+    }
+};
+
 #define SWG_Q32_RESET_GAP (1 << 29) // gap magnitude on reset rows: one such row zeroes A, G and B, two zero M
 
 // EDGES: one pass of a query longer than G*K columns, as in swg_diag_dyn_kernel: the left edge (M, B) of every
 // row comes from the previous pass's launch and the right edge goes to the next one, indexed by
 // 2 * (the row's position in the pair-major token order) + (which sequence of the pair), so that both
 // sequences of a pair can be items of the same launch; scores are the maximum over the passes.
-template <int K, int MAXW, bool EDGES>
+// EXACT: the cells of CellsX32 (gap scores of any sign; p.go / p.ge are then the signed scores) instead of the
+// reduced algebra; a third edge value (D) travels with the other two, through edge_d_in / edge_d_out between passes.
+template <int K, int MAXW, bool EDGES, bool EXACT = false>
 __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32Params p)
 {
     extern __shared__ __attribute__((aligned(256))) uint8_t smem[]; // int32 query profile, then the group records
@@ -1357,10 +1413,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     }
     __syncthreads();
 
-    CellsQ32<K> cells;
+    typename std::conditional<EXACT, CellsX32<K>, CellsQ32<K>>::type cells;
     cells.reset();
     uint32_t tok = 0u;
-    int m_out = 0, b_out = 0;
+    int m_out = 0, b_out = 0, d_out = 0; // right edge of the lane's strip: (M, B), or (L, B, D) in the exact form
     int go_v = (int)p.go, ge_v = (int)p.ge;
     uint32_t nlast = 0u;
     // v_perm selector of the leader: residue byte of X (.. 00) or Y (.. 01), zero, flags byte, zero.  It
@@ -1378,6 +1434,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     // current / next block (lanes 0..3 of a group, one row each)
     uint32_t rb_load = SWG_DYN_NONE, rb_nxt = SWG_DYN_NONE, rb_cur = SWG_DYN_NONE, ridx = SWG_DYN_NONE;
     int2 ec = make_int2(0, 0), en = make_int2(0, 0);
+    int ecd = 0, end_ = 0; // EXACT with EDGES: the third edge value of the current / next block
     uint32_t blocks = 0u, next_event = 0u, drain = 0u;
     bool hot = false;
     uint32_t rank;
@@ -1459,43 +1516,53 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
             rb_nxt = rb_load;
             if (rb_load != SWG_DYN_NONE) rb_load += 8u;
             ec = en;
+            ecd = end_;
             // lanes 0..3 of a group fetch the next block's left edges, one row each
             const uint32_t bq = quad_bcast(rb_nxt, 0);
             en = make_int2(0, 0);
-            if (g < 4 && bq != SWG_DYN_NONE && p.edge_in) en = p.edge_in[(size_t)bq + 2u * (uint32_t)g];
+            end_ = 0;
+            if (g < 4 && bq != SWG_DYN_NONE && p.edge_in) {
+                en = p.edge_in[(size_t)bq + 2u * (uint32_t)g];
+                if (EXACT) end_ = p.edge_d_in[(size_t)bq + 2u * (uint32_t)g];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             // the leader's token of this row: the residue byte of ITS sequence of the pair, and the flags
             const uint32_t raw = r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
             const uint32_t fresh = __builtin_amdgcn_perm(raw, raw, pick_cur);
-            uint32_t lm = 0u, lb = 0u, fresh_ridx = SWG_DYN_NONE;
+            uint32_t lm = 0u, lb = 0u, ld = 0u, fresh_ridx = SWG_DYN_NONE;
             if (EDGES) {
                 lm = quad_bcast((uint32_t)ec.x, r);
                 lb = quad_bcast((uint32_t)ec.y, r);
+                if (EXACT) ld = quad_bcast((uint32_t)ecd, r);
                 fresh_ridx = rb_cur != SWG_DYN_NONE ? rb_cur + 2u * (uint32_t)r : SWG_DYN_NONE;
             }
-            int em, eb;
+            int em, eb, ed = 0;
             const int Gs = opaque_uniform(G);
             if (Gs == 16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
                 em = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, (uint32_t)m_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)m_out));
                 eb = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, (uint32_t)b_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)b_out));
+                if (EXACT) ed = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(ld, (uint32_t)d_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)d_out));
                 if (EDGES) ridx = dpp_keep<DPP_ROW_SHR1>(fresh_ridx, ridx);
             } else {
                 const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
                 const uint32_t u1 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lm, (uint32_t)m_out) : dpp_zero<DPP_WAVE_SHR1>((uint32_t)m_out);
                 const uint32_t u2 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(lb, (uint32_t)b_out) : dpp_zero<DPP_WAVE_SHR1>((uint32_t)b_out);
+                const uint32_t u3 = !EXACT ? 0u : EDGES ? dpp_keep<DPP_WAVE_SHR1>(ld, (uint32_t)d_out) : dpp_zero<DPP_WAVE_SHR1>((uint32_t)d_out);
                 const uint32_t u4 = EDGES ? dpp_keep<DPP_WAVE_SHR1>(fresh_ridx, ridx) : 0u;
                 if (Gs == 32) { // lane 32 starts a group too
                     tok = leader ? fresh : u0;
                     em = leader ? (int)lm : (int)u1;
                     eb = leader ? (int)lb : (int)u2;
+                    if (EXACT) ed = leader ? (int)ld : (int)u3;
                     if (EDGES) ridx = leader ? fresh_ridx : u4;
                 } else {
                     tok = u0;
                     em = (int)u1;
                     eb = (int)u2;
+                    if (EXACT) ed = (int)u3;
                     if (EDGES) ridx = u4;
                 }
             }
@@ -1508,10 +1575,14 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                 uint32_t fm = 0u - ((tok >> 16) & 1u);
                 asm volatile("" : "+v"(fm)); // (keeps this a branch)
                 cells.best &= (int)~fm;
-                go_v = (int)(((uint32_t)go_v & ~fm) | (SWG_Q32_RESET_GAP & fm));
-                ge_v = (int)(((uint32_t)ge_v & ~fm) | (SWG_Q32_RESET_GAP & fm));
+                // (the reduced form subtracts gap magnitudes, the exact form adds signed gap scores)
+                const uint32_t rg = EXACT ? (uint32_t)-SWG_Q32_RESET_GAP : (uint32_t)SWG_Q32_RESET_GAP;
+                go_v = (int)(((uint32_t)go_v & ~fm) | (rg & fm));
+                ge_v = (int)(((uint32_t)ge_v & ~fm) | (rg & fm));
             }
-            const int2 e = cells.template row<(K > 12)>(prof_addr<0>(base, tok), em, eb, go_v, ge_v);
+            int2 e;
+            if constexpr (EXACT) e = cells.template row<(K > 12)>(prof_addr<0>(base, tok), em, eb, ed, go_v, ge_v, d_out);
+            else e = cells.template row<(K > 12)>(prof_addr<0>(base, tok), em, eb, go_v, ge_v);
             if (special) {
                 go_v = (int)p.go;
                 ge_v = (int)p.ge;
@@ -1533,7 +1604,10 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
             m_out = e.x;
             b_out = e.y;
             if (EDGES) {
-                if (tail && ridx != SWG_DYN_NONE && p.edge_out) p.edge_out[ridx] = e;
+                if (tail && ridx != SWG_DYN_NONE && p.edge_out) {
+                    p.edge_out[ridx] = e;
+                    if (EXACT) p.edge_d_out[ridx] = d_out;
+                }
             }
         }
         tp += tstep;
@@ -2095,9 +2169,15 @@ const DiagVariant *diag_variants(int *n)
 namespace {
 typedef void (*Q32Kernel)(const SwgDiagQ32Params);
 struct Q32Pair {
-    Q32Kernel single, edges;
+    Q32Kernel single, edges, exact_single, exact_edges;
 };
-template <int K, int MAXW> Q32Pair q32_kernel() { return Q32Pair{swg_diag32q_kernel<K, MAXW, false>, swg_diag32q_kernel<K, MAXW, true>}; }
+template <int K, int MAXW> Q32Pair q32_kernel()
+{
+    // (the exact cells hold more state per row: above 16 columns they are compiled for 12 wavefronts per CU, 170 registers)
+    constexpr int XW = K > 16 && MAXW > SWG_X32_WAVES_ABOVE16 ? SWG_X32_WAVES_ABOVE16 : MAXW;
+    return Q32Pair{swg_diag32q_kernel<K, MAXW, false>, swg_diag32q_kernel<K, MAXW, true>, swg_diag32q_kernel<K, XW, false, true>,
+                   swg_diag32q_kernel<K, XW, true, true>};
+}
 // one instantiation per K of the diagonal variants (same order: the variant index is shared)
 const Q32Pair *q32_kernels()
 {
@@ -2125,7 +2205,7 @@ size_t swg_diag32q_lds_bytes(int K, int G, int W)
     return (size_t)G * swg_q32_padded_cols(K) * 128u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
 }
 
-hipError_t swg_launch_diag32q(int variant, bool edges, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream)
+hipError_t swg_launch_diag32q(int variant, bool edges, bool exact, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream)
 {
     int n;
     const DiagVariant *v = diag_variants(&n);
@@ -2134,7 +2214,8 @@ hipError_t swg_launch_diag32q(int variant, bool edges, int W, int workgroups, co
         return hipErrorInvalidValue;
     const size_t lds = swg_diag32q_lds_bytes(v[variant].info.K, (int)p.G, W);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = edges ? q32_kernels()[variant].edges : q32_kernels()[variant].single;
+    const Q32Pair &kv = q32_kernels()[variant];
+    auto k = exact ? (edges ? kv.exact_edges : kv.exact_single) : (edges ? kv.edges : kv.single);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);

@@ -169,6 +169,39 @@ def test_q32_geometry_does_not_change_scores(swg, ctx, cols, group, waves):
     _reset_options(ctx)
 
 
+@pytest.mark.parametrize("gaps", [(5, -1), (0, 1), (1, -3), (2, 2), (-4, 3)])
+@pytest.mark.parametrize("opts", [{}, {"cols_per_wave": 7, "group_lanes": 16}, {"cols_per_wave": 28, "group_lanes": 32},
+                                  {"cols_per_wave": 16, "group_lanes": 64}, {"cols_per_wave": 3, "group_lanes": 64},
+                                  {"work_queue": 0}])
+def test_positive_gap_scores_through_the_work_queue(swg, ctx, orc, gaps, opts):
+    """Gap scores of any sign (the reference's CLI accepts positive ones, src/alignment_cmdline.c:255-267) run on the
+    exact cells of the int32 work-queue kernel: the reference's recurrence term by term, one pass or several (a
+    third edge value between the passes), any lane-group geometry up to 28 columns per lane; work_queue = 0 is
+    the older bin-based kernel.  Every score against the int32 oracle: two query lengths, sequences of 1 .. 700
+    residues, planted copies of the query."""
+    sc = swg.load_scoring("BLOSUM62")
+    go, ge = gaps
+    for lq, n in ((333, 700), (1700, 150)):
+        q = swg.synth_query(900 + lq, lq)
+        flat, off, _ = swg.synth_db(77 + lq, n, query=q, fraction=0.05, subst=0.2, min_len=1, max_len=700)
+        want = orc.score_db(q, flat, off, sc.table(), go, ge)
+        ctx.set_scoring(sc, go, ge)
+        ctx.set_query(q)
+        _reset_options(ctx)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        db = swg.Database(flat, off).upload(ctx)
+        got, hits, st = ctx.search(db, k=8)
+        assert np.array_equal(got, want), (gaps, opts, lq, st)
+        assert hits == orc.topk(want, 8) and st["path_bits"] == 32 and st["engine"] == 2
+        assert st["work_queue"] == (0 if "work_queue" in opts else 1)
+        if "cols_per_wave" in opts:
+            assert (st["cols_per_wave"], st["group_lanes"]) == (opts["cols_per_wave"], opts["group_lanes"])
+            assert st["passes"] == -(-lq // (opts["cols_per_wave"] * opts["group_lanes"]))
+        db.close()
+    _reset_options(ctx)
+
+
 @pytest.mark.parametrize("cols,maxw", [(32, 0), (16, 0), (48, 0), (24, 0), (32, 1), (32, 2), (16, 3), (32, 5), (24, 2)])
 def test_geometry_does_not_change_scores(swg, ctx, cols, maxw):
     """Strip width, wave count and the number of query passes are invisible in the result."""
