@@ -2409,14 +2409,14 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
 // bytes (swg_build_tokens16_kernel).  Nothing is un-transposed or re-coded on the host, and nothing is allocated or
 // freed per call once the buffers have grown to the size of the caller's macro-batches (round 2 rebuilt a whole
 // database per call: 26-34 ms of host work and hipFree around 2.5 ms of device time).  Returns 1 when the search
-// cannot take this route (options or gap scores that need the bin image): the caller falls back to the host route.
+// cannot take this route (options that ask for an engine that reads the bin image, a query the work-queue kernels
+// cannot hold): the caller falls back to the host route.
 static int fill_batches16_device(swg_ctx *ctx, const swg_batch16 *batches, size_t n_batches, size_t n_records,
                                  const size_t *first_rec, double *fill_seconds, double *t_ms)
 {
     typedef std::chrono::steady_clock clk;
     const clk::time_point t0 = clk::now();
-    const bool fast_ok = ctx->gap_open <= 0 && ctx->gap_extend <= 0 && -(ctx->gap_open + ctx->gap_extend) <= 32767;
-    if (!fast_ok || ctx->opt_engine == 1 || ctx->opt_dynamic == 0 || !ctx->have_scoring || ctx->query.empty()) return 1;
+    if (ctx->opt_engine == 1 || ctx->opt_dynamic == 0 || !ctx->have_scoring || ctx->query.empty()) return 1;
     for (const SwgSlot &sl : ctx->slots)
         if (sl.busy) return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_fill_batches16: searches are in flight on this context");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2645,7 +2645,7 @@ static int fill_batches16_impl(swg_ctx *ctx, const swg_batch16 *batches, size_t 
             return rd;
         }
     }
-    // the host route (searches the device route cannot take: positive gap scores, engine = 1, work_queue = 0)
+    // the host route (searches the device route cannot take: engine = 1, work_queue = 0, what needs the bin image)
     std::unique_ptr<int8_t[]> flat(new (std::nothrow) int8_t[std::max<uint64_t>(1, offsets.back())]);
     if (!flat) return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of host memory");
     swg_untranspose_batches16(batches, n_batches, first_rec.data(), offsets.data(), flat.get());

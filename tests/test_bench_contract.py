@@ -28,7 +28,7 @@ def _check_block(b, n_gpus=1):
 def test_committed_bench_line_has_the_contract_fields():
     """The default one-GPU line: headline = config 3, one block per configuration 2, 3, 4 (share), 5, and
     the whole 10M-sequence config 4 as the N = 1 point of the scaling curve."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                  ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("configs", dict)):
@@ -42,6 +42,13 @@ def test_committed_bench_line_has_the_contract_fields():
         assert b["config"]["workload"].startswith("config %s:" % k)
         _check_block(b)
     assert d["configs"]["3"]["value"] == d["value"]
+    # config 5 as BASELINE names it: one GPU's share of the 10M-sequence shape, and a leg that really re-scores
+    c5 = d["configs"]["5"]
+    assert c5["config"]["n_seqs"] == 1250000 and c5["rescore"]["n_rescored"] > 0 and c5["rescore"]["top_k_equals_main_leg"]
+    assert c5["rescore"]["kernel_ms"]["rescore"] > 0 and c5["rescore"]["options"] == {"wide16": 0}
+    for b in (d, d["configs"]["2"], d["configs"]["4"], d["scaling_reference"]):
+        assert b["dtype"] == "f16" and b["roofline"]["binding_roof"]["instr_per_cell"] == 4.25
+        assert b["roofline"]["traffic"] is None or b["roofline"]["traffic_source"].startswith("profiles/traffic.json@sha256:")
     ref = d["scaling_reference"]
     assert ref["config"]["n_seqs"] == 10000000 and "ONE" in ref["config"]["workload"]
     _check_block(ref)

@@ -82,16 +82,25 @@ def test_golden_forced_int32(swg, ctx, name, engine):
 @pytest.mark.parametrize("name", ["pam250_lq128", "blosum62_lq367", "pam250_partial_lanes",
                                   "blosum62_gap_0_1", "blosum62_gap_pos1_m3", "blosum62_query_bzx",
                                   "blosum62_gap_pos5_m1", "blosum62_gap_0_pos1"])
-def test_golden_through_reference_shaped_batches(swg, ctx, orc, name):
-    """swg_fill_batches16 replays exactly what alignment_fill_matrices receives."""
+@pytest.mark.parametrize("route", ["device", "host"])
+def test_golden_through_reference_shaped_batches(swg, ctx, orc, name, route):
+    """swg_fill_batches16 replays exactly what alignment_fill_matrices receives.  route "device": the batches are
+    uploaded as they are and the pair tokens built from them on the device, in buffers the context keeps between
+    calls (called three times: the second re-uses them, the third -- the batches in reverse order, so not sorted by
+    length -- as well); "host" (work_queue = 0 takes it): un-transposed and packed on the host as in round 2."""
     g = load_golden(name)
     _setup(ctx, g)
+    if route == "host":
+        ctx.set_option("work_queue", 0)
     batches = orc.db_to_batches16(g["flat"], g["offsets"])
     lanes = [int(v) for v in g["lanes"]]
-    out, secs = ctx.fill_batches16(list(zip(batches, lanes)))
-    for b, (o, nl) in enumerate(zip(out, lanes)):
-        assert np.array_equal(o, g["ref16"][b * 16:b * 16 + nl]), (name, b)
-    assert secs > 0
+    for attempt in range(3):
+        order = list(range(len(batches)))[::-1] if attempt == 2 else list(range(len(batches)))
+        out, secs = ctx.fill_batches16([(batches[b], lanes[b]) for b in order])
+        for o, b in zip(out, order):
+            assert np.array_equal(o, g["ref16"][b * 16:b * 16 + lanes[b]]), (name, route, attempt, b)
+        assert secs > 0
+    _reset_options(ctx)
 
 
 def test_overflow_is_detected_and_rescored(swg, ctx):
