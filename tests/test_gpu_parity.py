@@ -913,6 +913,59 @@ def test_config5_every_sequence_similar(swg, ctx, orc):
     db.close()
 
 
+def test_config5_one_gpu_share_with_flagged_rescore(swg, ctx, orc):
+    """Config 5 as BASELINE names it ("forcing 16->32-bit rescore") at one GPU's share of SURVEY 8d's shape: 1.25
+    million sequences, 1 % of them near-copies of the 8192-aa query (what bench.py's config-5 block and its `rescore`
+    leg run).  The wide int16 form (exact to 65535) and plain int16 + the flagged int32 re-score must agree on all
+    1 250 000 scores, the re-score must have run on exactly the planted sequences, and seeded samples are compared
+    with the REFERENCE (oracle/_ref: 16-record batches that hold no planted sequence -- its int16 lanes wrap above
+    32767) and with the int32 oracle (planted ones)."""
+    lq, n = 8192, 1250000
+    sc = swg.load_scoring("BLOSUM62")
+    tab = sc.table()
+    q = swg.synth_query(0x5EED0005, lq)
+    flat, off, planted = swg.synth_db(0x5EED0005, n, query=q, fraction=0.01, subst=0.05)
+    assert 11000 < planted < 14000
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    ctx.set_option("autotune", 0)
+    db = swg.Database(flat, off).upload(ctx)
+    wide, hits, st = ctx.search(db, k=100)
+    assert st["path_bits"] == 16 and st["cell_form"] == 1 and st["n_rescored"] == 0 and st["passes"] > 1
+    ctx.set_option("wide16", 0)
+    plain, hits16, st16 = ctx.search(db, k=100)
+    ctx.set_option("wide16", 1)
+    ctx.set_option("autotune", 1)
+    db.close()
+    big = wide > 32767
+    assert int(big.sum()) == planted and st16["n_rescored"] == planted and st16["rescore_ms"] > 0 and st16["cell_form"] == 0
+    assert np.array_equal(plain, wide) and hits16 == hits
+    order = np.lexsort((np.arange(n), -wide.astype(np.int64)))[:100]
+    assert hits == [(int(wide[i]), int(i)) for i in order]
+    rng = np.random.default_rng(5)
+    sample = rng.choice(np.nonzero(big)[0], size=24, replace=False)
+    s_off = np.zeros(len(sample) + 1, dtype=np.uint64)
+    s_off[1:] = np.cumsum([int(off[i + 1] - off[i]) for i in sample])
+    s_flat = np.concatenate([flat[int(off[i]):int(off[i + 1])] for i in sample])
+    assert np.array_equal(orc.score_db(q, s_flat, s_off, tab, -2, -1), wide[sample])
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref was not built (needs the reference sources at build time): planted sample checked only")
+    lens = np.diff(off.astype(np.int64))
+    srt = np.argsort(-lens, kind="stable")                  # the reference wants its input sorted by length (A.7-5)
+    groups = [g for g in rng.choice(n // 16, size=400, replace=False) if not big[srt[g * 16:g * 16 + 16]].any()][:200]
+    batches = []
+    for g in groups:
+        ids = srt[g * 16:g * 16 + 16]
+        b = np.full((int(lens[ids[0]]), 16), 31, dtype=np.int8)
+        for l, i in enumerate(ids):
+            b[:int(lens[i]), l] = flat[int(off[i]):int(off[i + 1])]
+        batches.append(b)
+    ref, _ = orc.ref_batches(q, batches, tab, -2, -1, threads=int(swg.lib.swg_host_threads()))
+    idx = np.concatenate([srt[g * 16:g * 16 + 16] for g in groups])
+    assert len(groups) >= 100 and np.array_equal(ref.astype(np.int32).ravel(), wide[idx])
+
+
 def test_config4_whole_database_on_one_gpu(swg, ctx, orc):
     """Config 4 as BASELINE names it: ONE 10M-sequence database (3000-aa query), all of it on this GPU (what
     bench.py's scaling reference runs).  A seeded sample of 16-record batches spread over the whole length
