@@ -2211,6 +2211,7 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
                 ctx->opt_group == 0 && ctx->opt_max_waves == 0 && ctx->opt_workgroups == 0;
     SwgDiagWork wk;
     const size_t Qb_max = 256; // queries per launch
+    uint64_t bound_max = 0;    // the largest score any query of the batch can reach
     if (fast) {
         // no score of any query may reach the int16 ceiling (the batch path has no re-score)
         int smax = 0;
@@ -2225,15 +2226,20 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
                 for (int b = 1; b < 32; ++b) best = std::max<int>(best, ctx->sub[(uint8_t)queries[j] & 31][b]);
                 qbound += (uint64_t)best;
             }
-            if (std::min<uint64_t>(qbound, std::min<uint64_t>(lq, longest) * (uint64_t)smax) >= 32767ull) fast = false;
+            const uint64_t bound = std::min<uint64_t>(qbound, std::min<uint64_t>(lq, longest) * (uint64_t)smax);
+            bound_max = std::max(bound_max, bound);
+            if (bound >= 32767ull) fast = false;
         }
     }
+    // the packed-f16 cells (8.5 instead of 10 instructions per column pair) where no query of the batch can reach
+    // their ceiling: the batch path has no re-run either
+    const int form = fast && ctx->opt_f16 != 0 && bound_max < 4096ull && -go <= 2048 && -ge <= 2048 ? 2 : 0;
     if (fast) {
         int rc = ensure_pair_tokens(ctx, const_cast<swg_db *>(db));
         if (rc != SWG_OK) return rc;
         fast = db->ptok.ok &&
                swg_plan_diag_work(db, lq_max, ctx->n_cu, 0, 0, 0, ctx->opt_long_split, true, true, &wk,
-                                  (double)std::min(n_queries, Qb_max)) > 0;
+                                  (double)std::min(n_queries, Qb_max), form) > 0;
         for (int c = 0; fast && c < wk.n_classes; ++c)
             fast = wk.plan[c].npass == 1 && diag_class_is_dynamic(ctx, db, wk.plan[c]) && (size_t)wk.plan[c].G * wk.plan[c].K >= lq_max;
     }
@@ -2313,7 +2319,7 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
             const SwgDiagPlan &pl = wk.plan[c];
             HIP_TRY(ctx, swg_launch_build_profiles_multi(ctx->d_sub, B.d_q, B.d_qoff, (uint32_t)Qb,
                                                          (uint32_t)(pl.G * swg_diag_padded_cols(pl.K)), pl.K,
-                                                         swg_diag_padded_cols(pl.K), B.d_prof[c], s, SWG_LDS_SWIZZLE ? pl.G : 0));
+                                                         swg_diag_padded_cols(pl.K), B.d_prof[c], s, SWG_LDS_SWIZZLE ? pl.G : 0, form == 2));
         }
         // workgroups per query: the chip's resident workgroups shared out over the batch
         int wgs[2] = {1, 1};
@@ -2352,15 +2358,15 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
             q.score_stride = n_slots;
             q.pair_limit = (uint32_t)(n_slots / 2);
             q.G = (uint32_t)pl.G;
-            q.go = gm | (gm << 16);
-            q.ge = em | (em << 16);
+            q.go = form == 2 ? f16x2_of(-go) : gm | (gm << 16);
+            q.ge = form == 2 ? f16x2_of(-ge) : em | (em << 16);
             if (c == 0) {
                 const uint64_t blocks = (uint64_t)(T.pair_blocks_prefix[wk.pair_end[0]] - T.pair_blocks_prefix[wk.pair_begin[0]]) * Qb;
                 q.prio_blocks = (uint32_t)std::max<uint64_t>(8, (uint64_t)(ctx->opt_prio_share * 0.01 * (double)blocks / (double)groups0));
             }
             q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
             q.simd_ranks = B.d_cnt + Qb_max * 2 * cnt_class + (size_t)c * SWG_DYN_SIMD_SLOTS;
-            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, false, 0, pl.W, wgs[c], q, c == 1 ? ctx->stream2 : s, (int)Qb));
+            HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, false, form, pl.W, wgs[c], q, c == 1 ? ctx->stream2 : s, (int)Qb));
         }
         if (wk.n_classes == 2) {
             HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[7], ctx->stream2));
@@ -2385,6 +2391,7 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
     st.engine = 2;
     st.work_queue = 1;
     st.classes_overlapped = -1; // (not measured for a batch)
+    st.cell_form = form;
     st.cols_per_wave = wk.plan[0].K;
     st.group_lanes = wk.plan[0].G;
     st.waves = wk.plan[0].W;

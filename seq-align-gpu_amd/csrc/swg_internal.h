@@ -171,7 +171,7 @@ hipError_t swg_launch_diag_dyn(int variant, bool edges, int form, int W, int wor
 // profile of ncols layout columns goes to d_profiles + i * ncols * 32 * 2 (int16)
 hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off,
                                            uint32_t n_queries, uint32_t ncols, int k_real, int k_padded,
-                                           uint8_t *d_profiles, hipStream_t stream, int swizzle_lanes = 0);
+                                           uint8_t *d_profiles, hipStream_t stream, int swizzle_lanes = 0, int f16 = 0);
 
 // LDS bank swizzle of the lane-group kernels' profile (1 = on): lane g of a group keeps the row of residue r
 // of each of its chunks at position r ^ (g & 31) instead of r, and forms its read address with an XOR instead

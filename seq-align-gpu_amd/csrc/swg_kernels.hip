@@ -1644,7 +1644,7 @@ __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query,
 // The same for several queries at once (swg_search_multi): grid.y = query; int16, 4-column chunks.
 __global__ void swg_build_profiles_multi_kernel(const int8_t *sub, const int8_t *queries, const uint32_t *q_off,
                                                 uint32_t ncols, uint32_t k_real, uint32_t k_padded, uint32_t swizzle_lanes,
-                                                uint8_t *out)
+                                                int f16, uint8_t *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
     if (t >= ncols * 32u) return;
@@ -1657,17 +1657,18 @@ __global__ void swg_build_profiles_multi_kernel(const int8_t *sub, const int8_t 
     const int v = pad ? 0 : (int)sub[(int)query[qcol] * 32 + (int)code];
     const uint32_t row = swizzle_lanes ? code ^ (((col / k_padded) % swizzle_lanes) & 31u) : code;
     const size_t e = (size_t)(col / 4u) * 128u + row * 4u + (col % 4u); // [col/4][32][4]
-    reinterpret_cast<int16_t *>(out + (size_t)qi * ncols * 64u)[e] = pad ? (int16_t)-32768 : (int16_t)v;
+    if (f16) reinterpret_cast<_Float16 *>(out + (size_t)qi * ncols * 64u)[e] = pad ? (_Float16)-65504.0f : (_Float16)(float)v;
+    else reinterpret_cast<int16_t *>(out + (size_t)qi * ncols * 64u)[e] = pad ? (int16_t)-32768 : (int16_t)v;
 }
 
 hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off,
                                            uint32_t n_queries, uint32_t ncols, int k_real, int k_padded,
-                                           uint8_t *d_profiles, hipStream_t stream, int swizzle_lanes)
+                                           uint8_t *d_profiles, hipStream_t stream, int swizzle_lanes, int f16)
 {
     if (n_queries == 0 || ncols == 0) return hipSuccess;
     hipLaunchKernelGGL(swg_build_profiles_multi_kernel, dim3((ncols * 32u + 255u) / 256u, n_queries), dim3(256), 0, stream,
                        d_sub, d_queries, d_q_off, ncols, (uint32_t)k_real, (uint32_t)k_padded, (uint32_t)swizzle_lanes,
-                       d_profiles);
+                       f16, d_profiles);
     return hipGetLastError();
 }
 
