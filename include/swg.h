@@ -94,7 +94,8 @@ typedef struct swg_stats {
     int32_t fill_launches;
     /* the cells the 16-bit fill ran on: 0 packed int16 (scores to 32767), 1 the wide int16 form (to 65535),
      * 2 packed f16 with gfx950's three-operand maxima (exact below 4096; a sequence that reaches it is
-     * flagged and re-scored in int32 like an int16 saturation) */
+     * flagged and re-scored in int32 like an int16 saturation), 3 (swg_search_multi only) the f16 cells with two
+     * QUERIES per lane against one sequence instead of two sequences against one query */
     int32_t cell_form;
 } swg_stats;
 
@@ -129,7 +130,8 @@ int swg_abi_version(void);
  * 16-bit fill runs on packed-f16 cells -- gfx950's three-operand maxima, 8.5 instead of 10 instructions per
  * column pair, exact below 4096, every sequence that reaches 4096 flagged and re-scored in int32 -- unless the
  * query is long enough for scores beyond 32767 or this database has flagged more than 2 % of its rows for this
- * query | 0: int16 cells only | 2: f16 cells whenever the gap magnitudes are at most 2048), "side_readout" (1 default:
+ * query | 0: int16 cells only | 2: f16 cells whenever the gap magnitudes are at most 2048), "qq" (1 default: a batch of
+ * queries on the f16 cells runs two queries per lane | 0: two sequences per lane as a single query does), "side_readout" (1 default:
  * top-K selection and read-out of a search run on their own stream, beside the fill of the search
  * queued next). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);

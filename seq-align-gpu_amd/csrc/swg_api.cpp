@@ -201,6 +201,8 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
     } else if (!strcmp(key, "f16")) {
         if (value < 0 || value > 2) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "f16 must be 0 (off), 1 (auto) or 2 (whenever the gap scores allow)");
         ctx->opt_f16 = value;
+    } else if (!strcmp(key, "qq")) {
+        ctx->opt_qq = value != 0;
     } else if (!strcmp(key, "long_helps")) {
         ctx->opt_long_helps = value != 0;
     } else if (!strcmp(key, "segment_blocks")) {
@@ -2114,6 +2116,7 @@ namespace {
 struct MultiBufs {
     int8_t *d_q = nullptr;
     uint32_t *d_qoff = nullptr;
+    uint32_t *d_order = nullptr;
     uint8_t *d_prof[2] = {nullptr, nullptr};
     int32_t *d_scores = nullptr;
     uint32_t *d_cnt = nullptr;
@@ -2121,6 +2124,7 @@ struct MultiBufs {
     {
         (void)hipFree(d_q);
         (void)hipFree(d_qoff);
+        (void)hipFree(d_order);
         (void)hipFree(d_prof[0]);
         (void)hipFree(d_prof[1]);
         (void)hipFree(d_scores);
@@ -2281,16 +2285,43 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
     }
 
     // ---- one launch per class for up to Qb_max queries ----------------------------------------
+    // Two queries per lane (swg_diag_qq_kernel, 7.5 instead of 8.5 instructions per column pair: the two halves of a
+    // register hold two QUERIES against one sequence, so no v_perm pairs two sequences' profile words) where the batch
+    // runs on the f16 cells and the pairs' 4-byte profile fits LDS beside the other class's; option "qq" = 0 turns it off.
+    bool qq = form == 2 && ctx->opt_qq != 0;
+    int qq_per_cu = 1;
+    if (qq) {
+        // The pairs' profile is twice the size, so LDS decides the occupancy (as for the int32 kernel): the long class
+        // keeps one workgroup of four wavefronts per CU, the bulk takes the workgroup size -- 4, 8, 12 or 16 wavefronts
+        // sharing one profile -- that leaves the most wavefronts resident (four 57 KB workgroups of four do not fit a
+        // CU; two of eight do: the first version of this path ran at two wavefronts per SIMD and lost to the perm).
+        size_t room = 160 * 1024;
+        const SwgKernelInfo info = swg_diag_variant_info(wk.plan[0].variant);
+        int cap_waves = info.max_waves;
+        if (wk.n_classes == 2) {
+            wk.plan[1].W = 4;
+            room -= std::min(room, swg_diag32q_lds_bytes(wk.plan[1].K, wk.plan[1].G, 4));
+            cap_waves -= 4;
+        }
+        int best_W = 0, best_waves = 0;
+        for (int W = 4; W <= info.max_waves; W += 4) {
+            const int n = std::min<int>((int)(room / swg_diag32q_lds_bytes(wk.plan[0].K, wk.plan[0].G, W)), cap_waves / W);
+            if (n >= 1 && n * W > best_waves) best_waves = n * W, best_W = W, qq_per_cu = n;
+        }
+        if (best_W == 0) qq = false; // (no room beside the long class: two sequences per lane, as before)
+        else wk.plan[0].W = best_W;
+    }
     const SwgPairTokens &T = db->ptok;
     const uint32_t gm = (uint32_t)(-go) & 0xFFFFu, em = (uint32_t)(-ge) & 0xFFFFu;
     const uint32_t cnt_class = SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE; // queue dwords of one class of one query
     MultiBufs B;
     std::vector<int32_t> h_scores;
-    std::vector<uint32_t> qoff32;
+    std::vector<uint32_t> qoff32, order;
     hipStream_t s = ctx->stream;
     ctx->cur = &ctx->slots[0];
     for (size_t q0 = 0; q0 < n_queries; q0 += Qb_max) {
         const size_t Qb = std::min(Qb_max, n_queries - q0);
+        const size_t Qrows = qq ? (Qb + 1) / 2 : Qb; // rows of the grid: query pairs, or queries
         const uint64_t qbytes = q_offsets[q0 + Qb] - q_offsets[q0];
         try {
             qoff32.resize(Qb + 1);
@@ -2299,27 +2330,43 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
             return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_search_multi: out of host memory");
         }
         for (size_t i = 0; i <= Qb; ++i) qoff32[i] = (uint32_t)(q_offsets[q0 + i] - q_offsets[q0]);
+        // qq: queries of similar length share a lane (row r of the score buffer belongs to query order[r] of this chunk)
+        order.resize(Qb);
+        for (size_t i = 0; i < Qb; ++i) order[i] = (uint32_t)i;
+        if (qq)
+            std::stable_sort(order.begin(), order.end(),
+                             [&](uint32_t a, uint32_t b) { return qoff32[a + 1] - qoff32[a] > qoff32[b + 1] - qoff32[b]; });
         if (q0 == 0) {
             const size_t cnt_dwords = Qb_max * 2 * cnt_class + 2 * SWG_DYN_SIMD_SLOTS;
             HIP_TRY(ctx, hipMalloc(&B.d_cnt, cnt_dwords * 4));
             HIP_TRY(ctx, hipMalloc(&B.d_scores, std::min(Qb_max, n_queries) * n_slots * 4));
             HIP_TRY(ctx, hipMalloc(&B.d_qoff, (Qb_max + 1) * 4));
-            for (int c = 0; c < wk.n_classes; ++c)
-                HIP_TRY(ctx, hipMalloc(&B.d_prof[c], std::min(Qb_max, n_queries) * (size_t)wk.plan[c].G *
-                                                         swg_diag_padded_cols(wk.plan[c].K) * 64));
+            HIP_TRY(ctx, hipMalloc(&B.d_order, Qb_max * 4));
+            for (int c = 0; c < wk.n_classes; ++c) {
+                // (qq: one profile of 128 bytes per column per query PAIR, and an odd batch's last pair is a whole pair)
+                const size_t rows_max = qq ? (std::min(Qb_max, n_queries) + 1) / 2 : std::min(Qb_max, n_queries);
+                const size_t per_row = (size_t)wk.plan[c].G * (qq ? (size_t)swg_q32_padded_cols(wk.plan[c].K) * 128 : (size_t)swg_diag_padded_cols(wk.plan[c].K) * 64);
+                HIP_TRY(ctx, hipMalloc(&B.d_prof[c], rows_max * per_row));
+            }
         }
         (void)hipFree(B.d_q);
         B.d_q = nullptr;
         HIP_TRY(ctx, hipMalloc(&B.d_q, std::max<uint64_t>(4, qbytes)));
         HIP_TRY(ctx, hipMemcpyAsync(B.d_q, queries + q_offsets[q0], qbytes, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(B.d_qoff, qoff32.data(), (Qb + 1) * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(B.d_order, order.data(), Qb * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemsetAsync(B.d_scores, 0, Qb * n_slots * 4, s));
         HIP_TRY(ctx, hipMemsetAsync(B.d_cnt, 0, (Qb_max * 2 * cnt_class + 2 * SWG_DYN_SIMD_SLOTS) * 4, s));
         for (int c = 0; c < wk.n_classes; ++c) {
             const SwgDiagPlan &pl = wk.plan[c];
-            HIP_TRY(ctx, swg_launch_build_profiles_multi(ctx->d_sub, B.d_q, B.d_qoff, (uint32_t)Qb,
-                                                         (uint32_t)(pl.G * swg_diag_padded_cols(pl.K)), pl.K,
-                                                         swg_diag_padded_cols(pl.K), B.d_prof[c], s, SWG_LDS_SWIZZLE ? pl.G : 0, form == 2));
+            if (qq)
+                HIP_TRY(ctx, swg_launch_build_profiles_qq(ctx->d_sub, B.d_q, B.d_qoff, B.d_order, (uint32_t)Qb,
+                                                          (uint32_t)(pl.G * swg_q32_padded_cols(pl.K)), pl.K, swg_q32_padded_cols(pl.K),
+                                                          B.d_prof[c], s, SWG_LDS_SWIZZLE ? pl.G : 0));
+            else
+                HIP_TRY(ctx, swg_launch_build_profiles_multi(ctx->d_sub, B.d_q, B.d_qoff, (uint32_t)Qb,
+                                                             (uint32_t)(pl.G * swg_diag_padded_cols(pl.K)), pl.K,
+                                                             swg_diag_padded_cols(pl.K), B.d_prof[c], s, SWG_LDS_SWIZZLE ? pl.G : 0, form == 2));
         }
         // workgroups per query: the chip's resident workgroups shared out over the batch
         int wgs[2] = {1, 1};
@@ -2327,14 +2374,14 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
         for (int c = 0; c < wk.n_classes; ++c) {
             const SwgDiagPlan &pl = wk.plan[c];
             const SwgKernelInfo info = swg_diag_variant_info(pl.variant);
-            const size_t lds = swg_diag_dyn_lds_bytes(pl.K, pl.G, pl.W);
-            const int per_cu = std::max(1, std::min<int>(info.max_waves / pl.W, (int)((160 * 1024) / lds)));
+            const size_t lds = qq ? swg_diag32q_lds_bytes(pl.K, pl.G, pl.W) : swg_diag_dyn_lds_bytes(pl.K, pl.G, pl.W);
+            const int per_cu = qq ? (c == 0 ? qq_per_cu : 1) : std::max(1, std::min<int>(info.max_waves / pl.W, (int)((160 * 1024) / lds)));
             int total = ctx->n_cu * per_cu;
-            if (wk.n_classes == 2) total = c == 1 ? ctx->n_cu : std::max(ctx->n_cu, total - ctx->n_cu); // one wavefront per SIMD for the long class
-            const uint64_t pairs = wk.pair_end[c] - wk.pair_begin[c];
+            if (wk.n_classes == 2 && !qq) total = c == 1 ? ctx->n_cu : std::max(ctx->n_cu, total - ctx->n_cu); // one wavefront per SIMD for the long class
+            const uint64_t items = (wk.pair_end[c] - wk.pair_begin[c]) * (qq ? 2u : 1u); // pairs, or (qq) single sequences
             const uint64_t per_wg = (uint64_t)pl.W * (64 / pl.G);
-            wgs[c] = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)total / Qb, (pairs + per_wg - 1) / per_wg));
-            if (c == 0) groups0 = (uint64_t)wgs[0] * Qb * per_wg;
+            wgs[c] = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)total / Qrows, (items + per_wg - 1) / per_wg));
+            if (c == 0) groups0 = (uint64_t)wgs[0] * Qrows * per_wg;
         }
         HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
         if (wk.n_classes == 2) {
@@ -2343,6 +2390,37 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
         }
         for (int c = wk.n_classes - 1; c >= 0; --c) {
             const SwgDiagPlan &pl = wk.plan[c];
+            if (qq) {
+                SwgDiagQQParams q;
+                memset(&q, 0, sizeof q);
+                q.tok = T.d_tok;
+                q.zero_block = (uint32_t)T.total_blocks;
+                q.pair_off = T.d_pair_off;
+                q.q_begin = (uint32_t)std::min<uint64_t>(2 * wk.pair_begin[c], n_slots);
+                q.q_end = (uint32_t)std::min<uint64_t>(2 * wk.pair_end[c], n_slots);
+                q.queue = B.d_cnt + (size_t)c * cnt_class;
+                q.queue_stride = 2 * cnt_class;
+                q.profile = B.d_prof[c];
+                q.profile_stride = (uint64_t)pl.G * swg_q32_padded_cols(pl.K) * 128;
+                q.scores = B.d_scores;
+                q.score_stride = n_slots;
+                q.n_queries = (uint32_t)Qb;
+                q.seq_limit = (uint32_t)n_slots;
+                q.G = (uint32_t)pl.G;
+                q.go = f16x2_of(-go);
+                q.ge = f16x2_of(-ge);
+                q.prio_blocks = 0xFFFFFFFFu;
+                if (c == 0) {
+                    const uint64_t blocks = 2ull * (uint64_t)(T.pair_blocks_prefix[wk.pair_end[0]] - T.pair_blocks_prefix[wk.pair_begin[0]]) * Qrows;
+                    q.prio_blocks = (uint32_t)std::max<uint64_t>(8, (uint64_t)(ctx->opt_prio_share * 0.01 * (double)blocks / (double)groups0));
+                } else {
+                    q.prio_blocks = 0u;
+                }
+                q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
+                q.simd_ranks = B.d_cnt + Qb_max * 2 * cnt_class + (size_t)c * SWG_DYN_SIMD_SLOTS;
+                HIP_TRY(ctx, swg_launch_diag_qq(pl.variant, pl.W, wgs[c], (int)Qrows, q, c == 1 ? ctx->stream2 : s));
+                continue;
+            }
             SwgDiagDynParams q;
             memset(&q, 0, sizeof q);
             q.tok = T.d_tok;
@@ -2380,18 +2458,20 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
         st.fill_ms += ms;
         st.total_ms += ms;
         const auto t0 = std::chrono::steady_clock::now();
-        for (size_t i = 0; i < Qb; ++i)
-            multi_deliver(db, h_scores.data() + i * n_slots, n_slots, scores_out ? scores_out + (q0 + i) * n_total : nullptr,
+        for (size_t r = 0; r < Qb; ++r) { // (row r of the score buffer = query order[r] of this chunk)
+            const size_t i = order[r];
+            multi_deliver(db, h_scores.data() + r * n_slots, n_slots, scores_out ? scores_out + (q0 + i) * n_total : nullptr,
                           topk_out ? topk_out + (q0 + i) * k : nullptr, k, n_hits ? n_hits + q0 + i : nullptr);
+        }
         st.topk_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        st.workgroups = wgs[0] * (int)Qb;
+        st.workgroups = wgs[0] * (int)Qrows;
         st.streams = (int32_t)groups0;
     }
     st.path_bits = 16;
     st.engine = 2;
     st.work_queue = 1;
     st.classes_overlapped = -1; // (not measured for a batch)
-    st.cell_form = form;
+    st.cell_form = qq ? 3 : form;
     st.cols_per_wave = wk.plan[0].K;
     st.group_lanes = wk.plan[0].G;
     st.waves = wk.plan[0].W;

@@ -128,6 +128,33 @@ struct SwgDiagQ32Params {
     const int32_t *edge_d_in;
     int32_t *edge_d_out;
 };
+// Two queries per lane against one sequence (swg_diag_qq_kernel): items are the sequences (sorted ranks)
+// [q_begin, q_end); row y of the grid works for query pair y.
+struct SwgDiagQQParams {
+    const uint4 *tok;         // pair-major token blocks
+    uint32_t zero_block;      // index of a block of zeros in tok
+    const uint32_t *pair_off; // [n_pairs+1]
+    uint32_t q_begin, q_end;  // ranks to score
+    uint32_t *queue;          // SWG_DYN_SHARDS counters per query pair (+ y * queue_stride dwords), zero before the launch
+    uint32_t queue_stride;
+    const uint8_t *profile;   // [G lanes][KP/2 chunks][32][2] x (2 queries x f16), + y * profile_stride bytes
+    uint64_t profile_stride;
+    int32_t *scores;          // query q's scores by sorted rank at scores + q * score_stride; pair y = queries 2y, 2y+1
+    uint64_t score_stride;
+    uint32_t n_queries;       // (an odd batch's last pair has no second query)
+    uint32_t seq_limit;       // ranks a score array has room for
+    uint32_t G;
+    uint32_t go, ge;          // |gap_open+gap_extend|, |gap_extend| as f16 numbers in both halves
+    uint32_t prio_blocks;     // a wavefront feeding a sequence of >= this many blocks runs at raised priority
+    uint32_t *simd_ranks;     // [SWG_DYN_SIMD_SLOTS] zero before the launch
+    uint32_t turn_levels;
+};
+hipError_t swg_launch_diag_qq(int variant, int W, int workgroups, int n_pairs, const SwgDiagQQParams &p, hipStream_t stream);
+// profiles of the query pairs (order[2y], order[2y+1]) of a batch: pair y's profile of ncols layout columns goes to
+// d_profiles + y * ncols * 32 * 4
+hipError_t swg_launch_build_profiles_qq(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off, const uint32_t *d_order,
+                                        uint32_t n_queries, uint32_t ncols, int k_real, int k_padded, uint8_t *d_profiles,
+                                        hipStream_t stream, int swizzle_lanes = 0);
 int swg_q32_padded_cols(int K);
 size_t swg_diag32q_lds_bytes(int K, int G, int W);
 // variant: index into the diagonal variants (swg_diag_variant_info gives its K)

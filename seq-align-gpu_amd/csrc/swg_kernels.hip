@@ -1455,6 +1455,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
         else __builtin_amdgcn_s_setprio(3);
     };
 
+    // (two loops, for 16-lane groups and for wider ones: see swg_diag_qq_kernel)
+    auto main_loop = [&](auto g16_tag) {
+    constexpr bool G16 = decltype(g16_tag)::value;
     for (;;) {
         if (blocks == next_event) {
             // some sequence has run out (or this is the start): its leader takes the next one
@@ -1539,8 +1542,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                 fresh_ridx = rb_cur != SWG_DYN_NONE ? rb_cur + 2u * (uint32_t)r : SWG_DYN_NONE;
             }
             int em, eb, ed = 0;
-            const int Gs = opaque_uniform(G);
-            if (Gs == 16) {
+            const int Gs = G16 ? 16 : opaque_uniform(G);
+            if (G16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
                 em = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, (uint32_t)m_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)m_out));
                 eb = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(lb, (uint32_t)b_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)b_out));
@@ -1614,6 +1617,280 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
         ++blocks;
         if (!hot) take_turn();
     }
+    };
+    if (G == 16) main_loop(std::true_type());
+    else main_loop(std::false_type());
+}
+
+// ---------------------------------------------------------------------------
+// Two QUERIES per lane against one sequence (batches of queries: swg_search_multi)
+// ---------------------------------------------------------------------------
+// Of the f16 cells' 8.5 instructions per column pair one is the v_perm_b32 that pairs the profile words of the two
+// SEQUENCES that share a lane: two residues, two LDS reads, one combine.  With a batch of queries the two halves of a
+// register can instead hold two queries against the SAME sequence: one residue, and a profile that keeps the two
+// queries' scores for a column side by side -- one ds_read_b64 is two columns ready to add.  7.5 instructions per two
+// cells.  Items are sequences (as in swg_diag32q_kernel: the token stream of the pair a sequence belongs to, the
+// leader lane picking its byte); row y of the grid works for query pair y.  Single pass, f16 cells (biased by -2048:
+// see CellsDiag FORM 2 for the arithmetic, the reset rows and the leader's edge registers); the host takes this path
+// only when no query of the batch can score 4096.
+template <int K> struct CellsQQ {
+    static constexpr int KP = (K + 1) / 2 * 2;
+    static constexpr int CHUNK = 32 * 2 * 4; // 256 bytes: 32 residues x 2 columns x (2 queries x f16)
+    uint32_t M[K], G[K], A[K];
+    uint32_t best, mdl;
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) M[k] = G[k] = A[k] = SWG_F16_ZERO;
+        best = SWG_F16_ZERO;
+        mdl = SWG_F16_ZERO;
+    }
+    DEVINL void wipe(uint32_t fm)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            M[k] = (M[k] & ~fm) | (SWG_F16_ZERO & fm);
+            G[k] = (G[k] & ~fm) | (SWG_F16_ZERO & fm);
+            A[k] = (A[k] & ~fm) | (SWG_F16_ZERO & fm);
+        }
+        best = (best & ~fm) | (SWG_F16_ZERO & fm);
+        mdl = (mdl & ~fm) | (SWG_F16_ZERO & fm);
+    }
+    DEVINL uint32_t best_is_huge() const { return 0u - (uint32_t)((((best & 0x78007800u) + 0x08000800u) & 0x80008000u) != 0u); }
+
+    template <bool FENCED = false> DEVINL uint2 row(uint32_t ax, uint32_t em, uint32_t eb, uint32_t go, uint32_t ge, uint32_t zero)
+    {
+        constexpr int NCH = KP / 2;
+        uint32_t md = mdl;
+        uint32_t gl = pk_sub_f16(em, go);
+        uint32_t bl = eb;
+        // (a chunk is two columns = 60 cycles of arithmetic, less than an LDS read takes: the reads run TWO chunks ahead)
+        uint2 n0 = lds_read_u2(ax), n1 = NCH > 1 ? lds_read_u2(ax + CHUNK) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint2 w = n0;
+            n0 = n1;
+            if (c + 2 < NCH) n1 = lds_read_u2(ax + (c + 2) * CHUNK);
+            const uint32_t s[2] = {w.x, w.y};
+            uint32_t mprev = 0u;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 2 * c + u;
+                if (k >= K) break; // unused tail of an odd K's last chunk
+                const uint32_t t = pk_add_f16(md, s[u]);
+                md = M[k];
+                const uint32_t a = pk_max3_f16(G[k], pk_sub_f16(A[k], ge), zero);
+                const uint32_t b = pk_max3_f16(gl, pk_sub_f16(bl, ge), zero);
+                const uint32_t m = pk_max3_f16(t, a, b);
+                M[k] = m;
+                A[k] = a;
+                gl = G[k] = pk_sub_f16(m, go);
+                bl = b;
+                if (u & 1) best = pk_max3_f16(best, mprev, m);
+                else if (k == K - 1) best = pk_max3_f16(best, m, m);
+                mprev = m;
+            }
+            if (FENCED && (c & 1) && c + 1 < NCH) __builtin_amdgcn_sched_barrier(0);
+        }
+        mdl = em;
+        return make_uint2(M[K - 1], bl);
+    }
+};
+
+template <int K, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQParams p)
+{
+    extern __shared__ __attribute__((aligned(256))) uint8_t smem[]; // the query pair's profile, then the group records
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int G = (int)p.G;
+    const int gshift = G == 16 ? 4 : G == 32 ? 5 : 6;
+    const int g = lane & (G - 1);
+    const bool leader = g == 0, tail = g == G - 1;
+    constexpr uint32_t Z = SWG_F16_ZERO;
+    const uint32_t base = prof_base(SWG_LDS_ADDRESS(smem) + (uint32_t)g * (CellsQQ<K>::KP / 2) * CellsQQ<K>::CHUNK, g);
+    const uint32_t slice = (uint32_t)G * CellsQQ<K>::KP * 128u;
+    auto record = [&]() -> uint32_t * {
+        const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        return reinterpret_cast<uint32_t *>(smem + slice) + (((uint32_t)w << (6 - gshift)) + (l >> gshift)) * SWG_DYN_STATE;
+    };
+    const uint8_t *profile = p.profile + (size_t)blockIdx.y * p.profile_stride;
+    uint32_t *const queue = p.queue + (size_t)blockIdx.y * p.queue_stride;
+    int32_t *const scores_a = p.scores + (size_t)(2u * blockIdx.y) * p.score_stride;      // first query of the pair
+    int32_t *const scores_b = p.scores + (size_t)(2u * blockIdx.y + 1u) * p.score_stride; // second (a copy of the first for an odd batch's last pair)
+    const bool have_b = 2u * blockIdx.y + 1u < p.n_queries;
+    for (uint32_t o = threadIdx.x * 16u; o < slice; o += blockDim.x * 16u)
+        *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(profile + o);
+    {
+        uint32_t *st = record();
+        if (g < 4) st[g] = 0u; // every group is due at block 0
+        for (uint32_t i = (uint32_t)g; i < 2u * SWG_DYN_RING; i += (uint32_t)G) st[SWG_DYN_MAXES + i] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n_items = p.q_end - p.q_begin;
+
+    CellsQQ<K> cells;
+    cells.reset();
+    uint32_t tok = 0u, m_out = Z, b_out = Z;
+    uint32_t em_rot[2] = {Z, Z}, eb_rot[2] = {Z, Z}; // (written only by the DPP moves: the leader keeps score 0, see swg_diag_dyn_kernel)
+    uint32_t zero_v = Z;
+    asm volatile("" : "+v"(zero_v));
+    uint32_t go_v = p.go, ge_v = p.ge;
+    uint32_t nlast = 0u;
+    // v_perm selector of the leader: residue byte of X (.. 00) or Y (.. 01), zero, flags byte, zero; the blocks in
+    // flight keep the selector they were loaded under (see swg_diag32q_kernel)
+    uint32_t pick = 0x0C020C00u, pick_nxt = 0x0C020C00u, pick_cur = 0x0C020C00u;
+    uint32_t T0 = 0u, T1 = 0u, T2 = 0u, T3 = 0u;
+    const uint32_t *const zero_blk = reinterpret_cast<const uint32_t *>(p.tok + p.zero_block);
+    const uint32_t *tp = zero_blk;
+    uint32_t tstep = 0u;
+    uint32_t blocks = 0u, next_event = 0u, drain = 0u;
+    bool hot = false;
+    uint32_t rank;
+    {
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((11 << 11) | (4 << 6) | 4);
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        const uint32_t simd = (((hw >> 4) << 2) | (hw & 3u) | (xcc << 10)) & (SWG_DYN_SIMD_SLOTS - 1u);
+        uint32_t r = 0u;
+        if (lane == 0) r = atomicAdd(p.simd_ranks + simd, 1u);
+        rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    }
+    auto take_turn = [&]() {
+        const uint32_t x = ((uint32_t)(wall_clock64() >> SWG_DYN_TURN_SHIFT) + rank) & 0xFFFFu;
+        const uint32_t turn = p.turn_levels == 4u ? (x & 3u) : x - 3u * ((x * 0xAAABu) >> 17);
+        if (turn == 0u) __builtin_amdgcn_s_setprio(0);
+        else if (turn == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (turn == 2u) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    };
+
+    // (the loop exists twice, for 16-lane groups and for wider ones, chosen once per launch: a run-time test of G inside the
+    // row makes the compiler issue BOTH hand-overs on every row -- three wave_shr moves and three selects, then, for 16
+    // lanes, three row_shr moves and five copies -- eleven instructions per row too many)
+    auto main_loop = [&](auto g16_tag) {
+    constexpr bool G16 = decltype(g16_tag)::value;
+    for (;;) {
+        if (blocks == next_event) {
+            __builtin_amdgcn_s_setprio(3);
+            uint32_t *st = record();
+            uint32_t end_at = st[0];
+            uint32_t fl = st[1];
+            if (leader && end_at == blocks) {
+                uint32_t tried = fl >> 8;
+                uint32_t item = SWG_DYN_NONE;
+                while (tried < SWG_DYN_SHARDS) {
+                    const uint32_t shard = (blockIdx.x + tried) & (SWG_DYN_SHARDS - 1u);
+                    const uint32_t cand = shard + SWG_DYN_SHARDS * atomicAdd(queue + shard * SWG_DYN_SHARD_STRIDE, 1u);
+                    if (cand < n_items) {
+                        item = cand;
+                        break;
+                    }
+                    ++tried;
+                }
+                fl = tried << 8;
+                const uint32_t seq = item != SWG_DYN_NONE ? p.q_begin + item : SWG_DYN_NONE;
+                if (seq != SWG_DYN_NONE && seq < p.seq_limit) {
+                    const uint32_t pr = seq >> 1;
+                    const uint32_t first = p.pair_off[pr];
+                    const uint32_t len = p.pair_off[pr + 1u] - first;
+                    tp = reinterpret_cast<const uint32_t *>(p.tok + first);
+                    tstep = 4u;
+                    end_at = blocks + len;
+                    pick = 0x0C020C00u | (seq & 1u);
+                    const uint32_t pushed = st[2];
+                    st[SWG_DYN_RING + (pushed & (SWG_DYN_RING - 1u))] = seq;
+                    st[2] = pushed + 1u;
+                    if (len >= p.prio_blocks) fl |= SWG_DYN_HOT;
+                } else {
+                    end_at = SWG_DYN_NONE;
+                    tp = zero_blk;
+                    tstep = 0u;
+                }
+                st[0] = end_at;
+                st[1] = fl;
+            }
+            next_event = SWG_DYN_NONE;
+            for (int i = 0; i < 64; i += G)
+                next_event = min(next_event, (uint32_t)__builtin_amdgcn_readlane((int)end_at, i));
+            hot = __builtin_amdgcn_ballot_w64(leader && end_at != SWG_DYN_NONE && (fl & SWG_DYN_HOT) != 0u) != 0ull;
+            if (!hot) take_turn();
+        }
+        if (next_event == SWG_DYN_NONE) {
+            if (drain >= (uint32_t)G + 12u) break;
+            drain += 4u;
+        }
+        pick_cur = pick_nxt;
+        pick_nxt = pick;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t raw = r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
+            const uint32_t fresh = __builtin_amdgcn_perm(raw, raw, pick_cur);
+            uint32_t em, eb;
+            const int Gs = G16 ? 16 : opaque_uniform(G);
+            if (G16) {
+                tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
+                em = em_rot[r & 1] = dpp_keep<DPP_ROW_SHR1>(em_rot[r & 1], m_out);
+                eb = eb_rot[r & 1] = dpp_keep<DPP_ROW_SHR1>(eb_rot[r & 1], b_out);
+            } else {
+                const uint32_t u0 = dpp_keep<DPP_WAVE_SHR1>(fresh, tok);
+                const uint32_t u1 = em_rot[r & 1] = dpp_keep<DPP_WAVE_SHR1>(em_rot[r & 1], m_out);
+                const uint32_t u2 = eb_rot[r & 1] = dpp_keep<DPP_WAVE_SHR1>(eb_rot[r & 1], b_out);
+                if (Gs == 32) { // lane 32 starts a group too
+                    tok = leader ? fresh : u0;
+                    em = leader ? Z : u1;
+                    eb = leader ? Z : u2;
+                } else {
+                    tok = u0;
+                    em = u1;
+                    eb = u2;
+                }
+            }
+            if (r == 0) T0 = tp[0];
+            else if (r == 1) T1 = tp[1];
+            else if (r == 2) T2 = tp[2];
+            else T3 = tp[3];
+            const bool special = __builtin_amdgcn_ballot_w64(tok > 0xFFFFu) != 0ull;
+            if (special) {
+                uint32_t fm = 0u - ((tok >> 16) & 1u);
+                asm volatile("" : "+v"(fm)); // (keeps this a branch)
+                const uint32_t fi = fm & cells.best_is_huge();
+                if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) cells.wipe(fi);
+                cells.best = (cells.best & ~fm) | (Z & fm);
+                go_v = (go_v & ~fm) | (SWG_F16_BIG & fm);
+                ge_v = (ge_v & ~fm) | (SWG_F16_BIG & fm);
+            }
+            const uint2 e = cells.template row<(K > 4)>(prof_addr<0>(base, tok), em, eb, go_v, ge_v, zero_v);
+            if (special) {
+                go_v = p.go;
+                ge_v = p.ge;
+                if (tok & SWG_TOK_LAST) {
+                    uint32_t *st = record();
+                    const uint32_t at = nlast & (SWG_DYN_RING - 1u);
+                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, f16_key(cells.best & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, f16_key(cells.best >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (tail) {
+                        const uint32_t seq = st[SWG_DYN_RING + at];
+                        const uint32_t sa = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t sb = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at + 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (seq < p.seq_limit) {
+                            scores_a[seq] = f16_score(sa);
+                            if (have_b) scores_b[seq] = f16_score(sb);
+                        }
+                    }
+                    ++nlast;
+                }
+            }
+            m_out = e.x;
+            b_out = e.y;
+        }
+        tp += tstep;
+        ++blocks;
+        if (!hot) take_turn();
+    }
+    };
+    if (G == 16) main_loop(std::true_type());
+    else main_loop(std::false_type());
 }
 
 // ---------------------------------------------------------------------------
@@ -1659,6 +1936,43 @@ __global__ void swg_build_profiles_multi_kernel(const int8_t *sub, const int8_t 
     const size_t e = (size_t)(col / 4u) * 128u + row * 4u + (col % 4u); // [col/4][32][4]
     if (f16) reinterpret_cast<_Float16 *>(out + (size_t)qi * ncols * 64u)[e] = pad ? (_Float16)-65504.0f : (_Float16)(float)v;
     else reinterpret_cast<int16_t *>(out + (size_t)qi * ncols * 64u)[e] = pad ? (int16_t)-32768 : (int16_t)v;
+}
+
+// Profiles of query PAIRS for swg_diag_qq_kernel: grid.y = pair; entry (column, residue) = the two queries' scores as
+// f16 numbers side by side (-65504 where a query has no such column), [col/2][32 residues][2 columns] x 4 bytes, rows
+// swizzled by the reading lane like the other lane-group profiles.  Pair y = queries 2y and 2y+1 of `order` (an odd
+// batch's last pair holds its query twice).
+__global__ void swg_build_profiles_qq_kernel(const int8_t *sub, const int8_t *queries, const uint32_t *q_off, const uint32_t *order,
+                                             uint32_t n_queries, uint32_t ncols, uint32_t k_real, uint32_t k_padded,
+                                             uint32_t swizzle_lanes, uint8_t *out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
+    if (t >= ncols * 32u) return;
+    const uint32_t col = t >> 5, code = t & 31u;
+    const uint32_t j = col % k_padded, qcol = (col / k_padded) * k_real + j;
+    uint32_t word = 0u;
+    for (uint32_t h = 0; h < 2u; ++h) {
+        const uint32_t qi = order[min(2u * blockIdx.y + h, n_queries - 1u)];
+        const int8_t *query = queries + q_off[qi];
+        const uint32_t lq = q_off[qi + 1u] - q_off[qi];
+        const bool pad = (j >= k_real) || (qcol >= lq) || (code == 0u);
+        const _Float16 v = pad ? (_Float16)-65504.0f : (_Float16)(float)sub[(int)query[qcol] * 32 + (int)code];
+        word |= (uint32_t)__builtin_bit_cast(unsigned short, v) << (16u * h);
+    }
+    const uint32_t row = swizzle_lanes ? code ^ (((col / k_padded) % swizzle_lanes) & 31u) : code;
+    const size_t e = (size_t)(col / 2u) * 64u + row * 2u + (col % 2u); // [col/2][32][2]
+    reinterpret_cast<uint32_t *>(out + (size_t)blockIdx.y * ncols * 128u)[e] = word;
+}
+
+hipError_t swg_launch_build_profiles_qq(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off, const uint32_t *d_order,
+                                        uint32_t n_queries, uint32_t ncols, int k_real, int k_padded, uint8_t *d_profiles,
+                                        hipStream_t stream, int swizzle_lanes)
+{
+    if (n_queries == 0 || ncols == 0) return hipSuccess;
+    hipLaunchKernelGGL(swg_build_profiles_qq_kernel, dim3((ncols * 32u + 255u) / 256u, (n_queries + 1u) / 2u), dim3(256), 0, stream,
+                       d_sub, d_queries, d_q_off, d_order, n_queries, ncols, (uint32_t)k_real, (uint32_t)k_padded,
+                       (uint32_t)swizzle_lanes, d_profiles);
+    return hipGetLastError();
 }
 
 hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_queries, const uint32_t *d_q_off,
@@ -2198,6 +2512,46 @@ const Q32Pair *q32_kernels()
     return v;
 }
 } // namespace
+
+namespace {
+typedef void (*QQKernel)(const SwgDiagQQParams);
+template <int K, int MAXW> QQKernel qq_kernel() { return swg_diag_qq_kernel<K, MAXW>; }
+// one instantiation per K of the diagonal variants (same order: the variant index is shared)
+const QQKernel *qq_kernels()
+{
+#ifdef SWG_PROBE_VARIANT
+    static const QQKernel v[] = {qq_kernel<SWG_PROBE_VARIANT>()};
+#else
+    static const QQKernel v[] = {
+        qq_kernel<24, 16>(), qq_kernel<12, 16>(), qq_kernel<8, 16>(), qq_kernel<16, 16>(), qq_kernel<32, 12>(),
+        qq_kernel<6, 16>(),  qq_kernel<10, 16>(), qq_kernel<20, 16>(), qq_kernel<28, 12>(), qq_kernel<4, 16>(),
+        qq_kernel<14, 16>(), qq_kernel<18, 16>(), qq_kernel<22, 16>(), qq_kernel<2, 16>(),
+        qq_kernel<23, 16>(), qq_kernel<21, 16>(), qq_kernel<19, 16>(), qq_kernel<17, 16>(), qq_kernel<15, 16>(),
+        qq_kernel<13, 16>(), qq_kernel<11, 16>(), qq_kernel<9, 16>(), qq_kernel<7, 16>(), qq_kernel<31, 12>(),
+        qq_kernel<29, 12>(), qq_kernel<27, 12>(), qq_kernel<25, 12>(), qq_kernel<30, 12>(), qq_kernel<26, 12>(),
+        qq_kernel<5, 16>(), qq_kernel<3, 16>(),
+    };
+#endif
+    return v;
+}
+} // namespace
+
+// (the query pairs' profile has the int32 profile's size: 4 bytes per column and residue)
+hipError_t swg_launch_diag_qq(int variant, int W, int workgroups, int n_pairs, const SwgDiagQQParams &p, hipStream_t stream)
+{
+    int n;
+    const DiagVariant *v = diag_variants(&n);
+    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 || n_pairs < 1 || n_pairs > 65535 ||
+        (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
+        return hipErrorInvalidValue;
+    const size_t lds = swg_diag32q_lds_bytes(v[variant].info.K, (int)p.G, W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = qq_kernels()[variant];
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(workgroups, n_pairs), dim3(W * 64), lds, stream, p);
+    return hipGetLastError();
+}
 
 int swg_q32_padded_cols(int K) { return (K + 1) / 2 * 2; }
 

@@ -16,7 +16,7 @@ def _setup(ctx, g):
 
 
 OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups", "segment_blocks")
-DEFAULT_ON = ("work_queue", "wide16", "f16")
+DEFAULT_ON = ("work_queue", "wide16", "f16", "qq")
 DEFAULT_OFF = ("long_helps",)
 
 
@@ -1072,6 +1072,33 @@ def test_many_queries_in_one_pass(swg, ctx, orc):
         ctx.search_multi(db2, [qs[0], np.zeros(0, np.int8)])            # an empty query is an error, not a crash
     db.close()
     db2.close()
+
+
+@pytest.mark.parametrize("opts,form", [({}, 3), ({"qq": 0}, 2), ({"f16": 0}, 0)])
+def test_many_queries_cell_forms(swg, ctx, orc, opts, form):
+    """The three forms a batch of queries can run on -- two QUERIES per lane on the f16 cells (the default where no
+    query of the batch can score 4096), two sequences per lane on the f16 cells, on the int16 cells -- give the
+    oracle's scores: odd numbers of queries and of sequences, a 1-residue query, a database with a long class."""
+    sc = swg.load_scoring("PAM250")
+    tab = sc.table()
+    ctx.set_scoring(sc, -3, -1)
+    ctx.set_query(swg.synth_query(1, 50))
+    for n, max_len, lens in ((1023, 900, (128, 1, 77, 300, 299, 45, 128)), (9001, 5000, (367, 200, 366))):
+        flat, off = swg.synth_db(70 + n, n, max_len=max_len)
+        _reset_options(ctx)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        db = swg.Database(flat, off).upload(ctx)
+        qs = [swg.synth_query(300 + i, L) for i, L in enumerate(lens)]
+        got, hits, st = ctx.search_multi(db, qs, k=4)
+        # (two queries per lane need twice the LDS per column: where the planner's wide lane groups for a small
+        # database leave no room for that, the batch stays on two sequences per lane)
+        assert st["cell_form"] == form or (form == 3 and n == 1023 and st["cell_form"] == 2), st
+        for i, q in enumerate(qs):
+            want = orc.score_db(q, flat, off, tab, -3, -1)
+            assert np.array_equal(got[i], want) and hits[i] == orc.topk(want, 4), (opts, n, i)
+        db.close()
+    _reset_options(ctx)
 
 
 def test_many_queries_fill_the_gpu_where_one_cannot(swg, ctx):
