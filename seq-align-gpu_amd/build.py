@@ -39,6 +39,7 @@ DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt",
                 "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 HIP_SOURCES = ["swg_kernels.hip", "swg_trace.hip", "swg_api.cpp", "swg_group.cpp"]
+KERNEL_PARTS = [0, 1, 2, 3, 4]  # swg_kernels.hip is compiled once per part (-DSWG_PART=n), in parallel
 CXX_SOURCES = ["swg_pack.cpp", "swg_diag_host.cpp"]  # host-only C++, OpenMP via g++
 C_SOURCES = ["swg_scoring.c", "swg_seqio.c", "swg_synth.c", "swg_threads.c"]
 CLI_SOURCES = ["sw_cmdline.c"]
@@ -70,6 +71,7 @@ def _headers():
 
 
 OBJDUMP = os.path.join(ROCM, "lib", "llvm", "bin", "llvm-objdump")
+FAMILIES = ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_diag32q_kernel", "swg_diag_qq_kernel")
 ISA_STAMP = os.path.join(OBJ, "isa_checked")
 
 
@@ -94,15 +96,14 @@ def verify_isa(lib=LIB):
                 m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
                 if m:
                     name = m.group(1)
-                    fam = next((f for f in ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_diag32q_kernel")
-                                if f in name), None)
+                    fam = next((f for f in FAMILIES if f in name), None)
                     continue
                 if fam and "ds_read" in line:
                     a, b = counts.get(fam, (0, 0))
                     counts[fam] = (a + ("ds_read_b64" in line), b + ("ds_read2_b64" in line))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for fam in ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_diag32q_kernel"):
+    for fam in FAMILIES:
         a, b = counts.get(fam, (0, 0))
         if a == 0 or b != 0:
             raise RuntimeError("%s: %d ds_read_b64 and %d ds_read2_b64 in the built kernels -- the load/store optimizer "
@@ -145,32 +146,40 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     hdrs = _headers() + [os.path.abspath(__file__)]
     objs = []
+    jobs = []  # (label, command) of everything that is out of date: run in parallel below
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src + ".o")
-        if force or _stale(o, [s] + hdrs):
-            if verbose:
-                print("[hipcc]", src)
-            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-c"]
-                 + DEVICE_FLAGS + ["-o", o, "-x", "hip", s])
-        objs.append(o)
+        # the kernel file is compiled once per PART (see its header): its ~350 kernel instantiations as one translation
+        # unit took four minutes, the parts side by side take as long as the largest of them
+        parts = KERNEL_PARTS if src == "swg_kernels.hip" else [None]
+        for part in parts:
+            o = os.path.join(OBJ, src + (".o" if part is None else ".part%d.o" % part))
+            if force or _stale(o, [s] + hdrs):
+                jobs.append(("[hipcc] " + src + ("" if part is None else " part %d" % part),
+                             [HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-c"] + DEVICE_FLAGS
+                             + ([] if part is None else ["-DSWG_PART=%d" % part]) + ["-o", o, "-x", "hip", s]))
+            objs.append(o)
     for src in CXX_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src + ".o")
         if force or _stale(o, [s] + hdrs):
-            if verbose:
-                print("[g++]", src)
-            _run(["g++", "-O2", "-fPIC", "-fopenmp", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
-                  "-I" + os.path.join(ROCM, "include"), "-c", "-o", o, s])
+            jobs.append(("[g++] " + src, ["g++", "-O2", "-fPIC", "-fopenmp", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                                          "-I" + os.path.join(ROCM, "include"), "-c", "-o", o, s]))
         objs.append(o)
     for src in C_SOURCES:
         s = os.path.join(HOST, src)
         o = os.path.join(OBJ, src + ".o")
         if force or _stale(o, [s] + hdrs):
-            if verbose:
-                print("[gcc]", src)
-            _run(["gcc", "-O2", "-fPIC", "-fopenmp", "-std=c11", "-Wall", "-c", "-o", o, s])
+            jobs.append(("[gcc] " + src, ["gcc", "-O2", "-fPIC", "-fopenmp", "-std=c11", "-Wall", "-c", "-o", o, s]))
         objs.append(o)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        if verbose:
+            for label, _ in jobs:
+                print(label)
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 4)))) as pool:
+            for _ in pool.map(lambda j: _run(j[1]), jobs):   # (the first failure is raised here)
+                pass
     if force or _stale(LIB, objs):
         if verbose:
             print("[link] libswg.so")

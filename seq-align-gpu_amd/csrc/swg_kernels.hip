@@ -53,6 +53,28 @@
 #include "swg_internal.h"
 #include <type_traits>
 
+// This file is compiled several times, once per PART (build.py, in parallel: one translation unit with all of its
+// ~350 kernel instantiations took four minutes): every part sees all the templates and instantiates one family.
+//   0  the non-template kernels, the systolic fill, the fixed-stream diagonal fill, the bin-based int32 fill and the
+//      launchers that only choose among other parts' kernels
+//   1  swg_diag_dyn_kernel on the int16 and wide cells     2  swg_diag_dyn_kernel on the f16 cells
+//   3  swg_diag32q_kernel (reduced and exact cells)        4  swg_diag_qq_kernel
+// Undefined: everything in one unit (tools/probe_isa.sh with SWG_PROBE_VARIANT).
+#ifdef SWG_PART
+#define SWG_HAS_PART(n) (SWG_PART == (n))
+#else
+#define SWG_HAS_PART(n) 1
+#endif
+// The (K, wave budget) instantiations of the lane-group kernels; the position in this list is the variant index.
+#ifdef SWG_PROBE_VARIANT // (ISA experiments on one instantiation: tools/probe_isa.sh)
+#define SWG_DIAG_VARIANTS(X) X(SWG_PROBE_VARIANT)
+#else
+#define SWG_DIAG_VARIANTS(X)                                                                                          \
+    X(24, 16) X(12, 16) X(8, 16) X(16, 16) X(32, 12) X(6, 16) X(10, 16) X(20, 16) X(28, 12) X(4, 16) X(14, 16) X(18, 16) \
+    X(22, 16) X(2, 16) X(23, 16) X(21, 16) X(19, 16) X(17, 16) X(15, 16) X(13, 16) X(11, 16) X(9, 16) X(7, 16) X(31, 12)  \
+    X(29, 12) X(27, 12) X(25, 12) X(30, 12) X(26, 12) X(5, 16) X(3, 16)
+#endif
+
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -1893,6 +1915,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
     else main_loop(std::false_type());
 }
 
+#if SWG_HAS_PART(0)
 // ---------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------
@@ -2121,6 +2144,8 @@ __global__ void swg_collect_saturated_kernel(const int32_t *scores, uint32_t n, 
     }
 }
 
+#endif // part 0
+
 // ---------------------------------------------------------------------------
 // The int32 diagonal fill: 64 lanes share ONE sequence, exact recurrence
 // ---------------------------------------------------------------------------
@@ -2277,6 +2302,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32_kernel(const SwgFillPara
     }
 }
 
+#if SWG_HAS_PART(0)
 // ---------------------------------------------------------------------------
 // device top-K: histogram -> threshold -> compaction of the few candidates
 // ---------------------------------------------------------------------------
@@ -2388,9 +2414,85 @@ hipError_t swg_launch_topk(const int32_t *d_scores, const uint32_t *d_order, uin
     return hipGetLastError();
 }
 
+#endif // part 0
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+typedef void (*SwgDynKernel)(const SwgDiagDynParams);
+typedef void (*SwgQ32Kernel)(const SwgDiagQ32Params);
+typedef void (*SwgQQKernel)(const SwgDiagQQParams);
+// kernel of a variant, from the part that instantiates it: which = 0 single pass / 1 one pass of several / 2 the same,
+// wide form (int16 cells); 0 single pass / 1 one pass of several (f16 cells)
+SwgDynKernel swg_dyn_kernel_i16(int variant, int which);
+SwgDynKernel swg_dyn_kernel_f16(int variant, int which);
+
+#if SWG_HAS_PART(1)
+SwgDynKernel swg_dyn_kernel_i16(int variant, int which)
+{
+#define SWG_ROW(K, W) {swg_diag_dyn_kernel<K, W, false, 0>, swg_diag_dyn_kernel<K, W, true, 0>, swg_diag_dyn_kernel<K, W, true, 1>},
+    static const SwgDynKernel t[][3] = {SWG_DIAG_VARIANTS(SWG_ROW)};
+#undef SWG_ROW
+    return t[variant][which];
+}
+#endif
+
+#if SWG_HAS_PART(2)
+SwgDynKernel swg_dyn_kernel_f16(int variant, int which)
+{
+#define SWG_ROW(K, W) {swg_diag_dyn_kernel<K, W, false, 2>, swg_diag_dyn_kernel<K, W, true, 2>},
+    static const SwgDynKernel t[][2] = {SWG_DIAG_VARIANTS(SWG_ROW)};
+#undef SWG_ROW
+    return t[variant][which];
+}
+#endif
+
+#if SWG_HAS_PART(3)
+// (the exact cells hold more state per row: above 16 columns they are compiled for 12 wavefronts per CU, 170 registers)
+template <int K, int MAXW> struct SwgX32Waves {
+    static constexpr int value = K > 16 && MAXW > SWG_X32_WAVES_ABOVE16 ? SWG_X32_WAVES_ABOVE16 : MAXW;
+};
+hipError_t swg_launch_diag32q(int variant, bool edges, bool exact, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream)
+{
+#define SWG_ROW(K, W)                                                                                                              \
+    {swg_diag32q_kernel<K, W, false>, swg_diag32q_kernel<K, W, true>, swg_diag32q_kernel<K, SwgX32Waves<K, W>::value, false, true>, \
+     swg_diag32q_kernel<K, SwgX32Waves<K, W>::value, true, true>},
+    static const SwgQ32Kernel t[][4] = {SWG_DIAG_VARIANTS(SWG_ROW)};
+#undef SWG_ROW
+    if (variant < 0 || variant >= swg_num_diag_variants() || W < 1 || W > swg_diag_variant_info(variant).max_waves || workgroups < 1 ||
+        (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
+        return hipErrorInvalidValue;
+    const size_t lds = swg_diag32q_lds_bytes(swg_diag_variant_info(variant).K, (int)p.G, W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = t[variant][(exact ? 2 : 0) + (edges ? 1 : 0)];
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
+    return hipGetLastError();
+}
+#endif
+
+#if SWG_HAS_PART(4)
+// (the query pairs' profile has the int32 profile's size: 4 bytes per column and residue)
+hipError_t swg_launch_diag_qq(int variant, int W, int workgroups, int n_pairs, const SwgDiagQQParams &p, hipStream_t stream)
+{
+#define SWG_ROW(K, W) swg_diag_qq_kernel<K, W>,
+    static const SwgQQKernel t[] = {SWG_DIAG_VARIANTS(SWG_ROW)};
+#undef SWG_ROW
+    if (variant < 0 || variant >= swg_num_diag_variants() || W < 1 || W > swg_diag_variant_info(variant).max_waves || workgroups < 1 ||
+        n_pairs < 1 || n_pairs > 65535 || (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
+        return hipErrorInvalidValue;
+    const size_t lds = swg_diag32q_lds_bytes(swg_diag_variant_info(variant).K, (int)p.G, W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = t[variant];
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(workgroups, n_pairs), dim3(W * 64), lds, stream, p);
+    return hipGetLastError();
+}
+#endif
+
+#if SWG_HAS_PART(0)
 namespace {
 struct Variant {
     SwgKernelInfo info;
@@ -2432,149 +2534,28 @@ const Variant *variants32(int *n)
     return v;
 }
 const Variant *variants(int bits, int *n) { return bits == 16 ? variants16(n) : variants32(n); }
-} // namespace
 
-namespace {
+// the fixed-stream diagonal fill: [0] single pass, [1] multi-pass, [2] multi-pass wide form (also runs one pass)
+typedef void (*DiagKernel)(const SwgDiagParams);
 struct DiagVariant {
-    SwgKernelInfo info;
-    void (*kernel[2])(const SwgDiagParams); // [0] single pass, [1] multi-pass
-    void (*wide)(const SwgDiagParams);      // multi-pass form (also runs one pass), scores to 65535
-    void (*dyn[5])(const SwgDiagDynParams); // pairs off a work queue: single pass; one pass of several; the same, wide form; f16 cells: single pass; one pass of several
+    int K, max_waves;
+    DiagKernel kernel[3];
 };
-template <int K, int MAXW> DiagVariant make_diag()
-{
-    DiagVariant v;
-    v.info.bits = 16;
-    v.info.K = K;
-    v.info.max_waves = MAXW;
-    v.info.nb = 2;
-    v.info.elem_size = 2;
-    v.info.lds_per_wave = 0;
-    v.info.lds_fixed = 0;
-    v.kernel[0] = swg_diag_kernel<K, MAXW, false>;
-    v.kernel[1] = swg_diag_kernel<K, MAXW, true>;
-    v.wide = swg_diag_kernel<K, MAXW, true, true>;
-    v.dyn[0] = swg_diag_dyn_kernel<K, MAXW, false, 0>;
-    v.dyn[1] = swg_diag_dyn_kernel<K, MAXW, true, 0>;
-    v.dyn[2] = swg_diag_dyn_kernel<K, MAXW, true, 1>;
-    v.dyn[3] = swg_diag_dyn_kernel<K, MAXW, false, 2>;
-    v.dyn[4] = swg_diag_dyn_kernel<K, MAXW, true, 2>;
-    return v;
-}
 const DiagVariant *diag_variants(int *n)
 {
-#ifdef SWG_PROBE_VARIANT // (ISA experiments on one instantiation: tools/probe_isa.sh)
-    static const DiagVariant v[] = {make_diag<SWG_PROBE_VARIANT>()};
-#else
-    static const DiagVariant v[] = {
-        make_diag<24, 16>(), make_diag<12, 16>(), make_diag<8, 16>(), make_diag<16, 16>(), make_diag<32, 12>(),
-        make_diag<6, 16>(),  make_diag<10, 16>(), make_diag<20, 16>(), make_diag<28, 12>(), make_diag<4, 16>(),
-        make_diag<14, 16>(), make_diag<18, 16>(), make_diag<22, 16>(), make_diag<2, 16>(),
-        make_diag<23, 16>(), make_diag<21, 16>(), make_diag<19, 16>(), make_diag<17, 16>(), make_diag<15, 16>(),
-        make_diag<13, 16>(), make_diag<11, 16>(), make_diag<9, 16>(), make_diag<7, 16>(), make_diag<31, 12>(),
-        make_diag<29, 12>(), make_diag<27, 12>(), make_diag<25, 12>(), make_diag<30, 12>(), make_diag<26, 12>(),
-        make_diag<5, 16>(), make_diag<3, 16>(),
-    };
-#endif
+#define SWG_ROW(K, W) {K, W, {swg_diag_kernel<K, W, false>, swg_diag_kernel<K, W, true>, swg_diag_kernel<K, W, true, true>}},
+    static const DiagVariant v[] = {SWG_DIAG_VARIANTS(SWG_ROW)};
+#undef SWG_ROW
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
 }
 } // namespace
-
-namespace {
-typedef void (*Q32Kernel)(const SwgDiagQ32Params);
-struct Q32Pair {
-    Q32Kernel single, edges, exact_single, exact_edges;
-};
-template <int K, int MAXW> Q32Pair q32_kernel()
-{
-    // (the exact cells hold more state per row: above 16 columns they are compiled for 12 wavefronts per CU, 170 registers)
-    constexpr int XW = K > 16 && MAXW > SWG_X32_WAVES_ABOVE16 ? SWG_X32_WAVES_ABOVE16 : MAXW;
-    return Q32Pair{swg_diag32q_kernel<K, MAXW, false>, swg_diag32q_kernel<K, MAXW, true>, swg_diag32q_kernel<K, XW, false, true>,
-                   swg_diag32q_kernel<K, XW, true, true>};
-}
-// one instantiation per K of the diagonal variants (same order: the variant index is shared)
-const Q32Pair *q32_kernels()
-{
-#ifdef SWG_PROBE_VARIANT
-    static const Q32Pair v[] = {q32_kernel<SWG_PROBE_VARIANT>()};
-#else
-    static const Q32Pair v[] = {
-        q32_kernel<24, 16>(), q32_kernel<12, 16>(), q32_kernel<8, 16>(), q32_kernel<16, 16>(), q32_kernel<32, 12>(),
-        q32_kernel<6, 16>(),  q32_kernel<10, 16>(), q32_kernel<20, 16>(), q32_kernel<28, 12>(), q32_kernel<4, 16>(),
-        q32_kernel<14, 16>(), q32_kernel<18, 16>(), q32_kernel<22, 16>(), q32_kernel<2, 16>(),
-        q32_kernel<23, 16>(), q32_kernel<21, 16>(), q32_kernel<19, 16>(), q32_kernel<17, 16>(), q32_kernel<15, 16>(),
-        q32_kernel<13, 16>(), q32_kernel<11, 16>(), q32_kernel<9, 16>(), q32_kernel<7, 16>(), q32_kernel<31, 12>(),
-        q32_kernel<29, 12>(), q32_kernel<27, 12>(), q32_kernel<25, 12>(), q32_kernel<30, 12>(), q32_kernel<26, 12>(),
-        q32_kernel<5, 16>(), q32_kernel<3, 16>(),
-    };
-#endif
-    return v;
-}
-} // namespace
-
-namespace {
-typedef void (*QQKernel)(const SwgDiagQQParams);
-template <int K, int MAXW> QQKernel qq_kernel() { return swg_diag_qq_kernel<K, MAXW>; }
-// one instantiation per K of the diagonal variants (same order: the variant index is shared)
-const QQKernel *qq_kernels()
-{
-#ifdef SWG_PROBE_VARIANT
-    static const QQKernel v[] = {qq_kernel<SWG_PROBE_VARIANT>()};
-#else
-    static const QQKernel v[] = {
-        qq_kernel<24, 16>(), qq_kernel<12, 16>(), qq_kernel<8, 16>(), qq_kernel<16, 16>(), qq_kernel<32, 12>(),
-        qq_kernel<6, 16>(),  qq_kernel<10, 16>(), qq_kernel<20, 16>(), qq_kernel<28, 12>(), qq_kernel<4, 16>(),
-        qq_kernel<14, 16>(), qq_kernel<18, 16>(), qq_kernel<22, 16>(), qq_kernel<2, 16>(),
-        qq_kernel<23, 16>(), qq_kernel<21, 16>(), qq_kernel<19, 16>(), qq_kernel<17, 16>(), qq_kernel<15, 16>(),
-        qq_kernel<13, 16>(), qq_kernel<11, 16>(), qq_kernel<9, 16>(), qq_kernel<7, 16>(), qq_kernel<31, 12>(),
-        qq_kernel<29, 12>(), qq_kernel<27, 12>(), qq_kernel<25, 12>(), qq_kernel<30, 12>(), qq_kernel<26, 12>(),
-        qq_kernel<5, 16>(), qq_kernel<3, 16>(),
-    };
-#endif
-    return v;
-}
-} // namespace
-
-// (the query pairs' profile has the int32 profile's size: 4 bytes per column and residue)
-hipError_t swg_launch_diag_qq(int variant, int W, int workgroups, int n_pairs, const SwgDiagQQParams &p, hipStream_t stream)
-{
-    int n;
-    const DiagVariant *v = diag_variants(&n);
-    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 || n_pairs < 1 || n_pairs > 65535 ||
-        (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
-        return hipErrorInvalidValue;
-    const size_t lds = swg_diag32q_lds_bytes(v[variant].info.K, (int)p.G, W);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = qq_kernels()[variant];
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(workgroups, n_pairs), dim3(W * 64), lds, stream, p);
-    return hipGetLastError();
-}
 
 int swg_q32_padded_cols(int K) { return (K + 1) / 2 * 2; }
 
 size_t swg_diag32q_lds_bytes(int K, int G, int W)
 {
     return (size_t)G * swg_q32_padded_cols(K) * 128u + (size_t)W * (64 / G) * SWG_DYN_STATE * 4u;
-}
-
-hipError_t swg_launch_diag32q(int variant, bool edges, bool exact, int W, int workgroups, const SwgDiagQ32Params &p, hipStream_t stream)
-{
-    int n;
-    const DiagVariant *v = diag_variants(&n);
-    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
-        (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
-        return hipErrorInvalidValue;
-    const size_t lds = swg_diag32q_lds_bytes(v[variant].info.K, (int)p.G, W);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const Q32Pair &kv = q32_kernels()[variant];
-    auto k = exact ? (edges ? kv.exact_edges : kv.exact_single) : (edges ? kv.edges : kv.single);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
-    return hipGetLastError();
 }
 
 int swg_num_diag_variants()
@@ -2587,7 +2568,16 @@ int swg_num_diag_variants()
 SwgKernelInfo swg_diag_variant_info(int variant)
 {
     int n;
-    return diag_variants(&n)[variant].info;
+    const DiagVariant &d = diag_variants(&n)[variant];
+    SwgKernelInfo info;
+    info.bits = 16;
+    info.K = d.K;
+    info.max_waves = d.max_waves;
+    info.nb = 2;
+    info.elem_size = 2;
+    info.lds_per_wave = 0;
+    info.lds_fixed = 0;
+    return info;
 }
 
 hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int workgroups, size_t lds_bytes,
@@ -2595,10 +2585,10 @@ hipError_t swg_launch_diag(int variant, bool multipass, bool wide, int W, int wo
 {
     int n;
     const DiagVariant *v = diag_variants(&n);
-    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
+    if (variant < 0 || variant >= n || W < 1 || W > v[variant].max_waves || workgroups < 1 ||
         (p.G != 16 && p.G != 32 && p.G != 64))
         return hipErrorInvalidValue;
-    auto k = wide ? v[variant].wide : v[variant].kernel[multipass ? 1 : 0];
+    auto k = wide ? v[variant].kernel[2] : v[variant].kernel[multipass ? 1 : 0];
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -2619,12 +2609,12 @@ hipError_t swg_launch_diag_dyn(int variant, bool edges, int form, int W, int wor
     if (n_queries < 1 || n_queries > 65535) return hipErrorInvalidValue;
     int n;
     const DiagVariant *v = diag_variants(&n);
-    if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1 ||
+    if (variant < 0 || variant >= n || W < 1 || W > v[variant].max_waves || workgroups < 1 ||
         (p.G != 16 && p.G != 32 && p.G != 64) || p.q_end < p.q_begin)
         return hipErrorInvalidValue;
-    const size_t lds = swg_diag_dyn_lds_bytes(v[variant].info.K, (int)p.G, W);
+    const size_t lds = swg_diag_dyn_lds_bytes(v[variant].K, (int)p.G, W);
     if (form < 0 || form > 2 || (form == 1 && !edges)) return hipErrorInvalidValue;
-    auto k = v[variant].dyn[form == 2 ? (edges ? 4 : 3) : form == 1 ? 2 : edges ? 1 : 0];
+    auto k = form == 2 ? swg_dyn_kernel_f16(variant, edges ? 1 : 0) : swg_dyn_kernel_i16(variant, form == 1 ? 2 : edges ? 1 : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -2739,3 +2729,4 @@ hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slot
                        stream, d_scores, n_slots, ceiling, d_list, d_count, d_lens, d_lens ? d_rows16 : nullptr);
     return hipGetLastError();
 }
+#endif // part 0
