@@ -316,7 +316,8 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
     block = None
     if env.rank == 0:
         gcups = cells_total * steps / elapsed / 1e9
-        roofline, dtype = roofline_of(a, last, fill_ms, cells_local, cnum, sharded)
+        whole = sharded or n == cfg.get("n_full")   # (the whole database of a configuration whose usual block is one GPU's share)
+        roofline, dtype = roofline_of(a, last, fill_ms, cells_local, cnum, whole)
         step_fill_ms = float(np.mean(fill_ms))
         if sharded:
             workload = ("config %d: 1 query (%d aa) vs ONE %d-seq synthetic protein DB dealt by bins over %d GPU(s), "
@@ -355,7 +356,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
         l_steps = max(2, steps)
         l_elapsed, l_fill, l_total, l_sts, l_hits = timed(l_steps, min(warmup, 2))
         if env.rank == 0:
-            l_roof, l_dtype = roofline_of(a, l_sts[-1], l_fill, cells_local, cnum, sharded)
+            l_roof, l_dtype = roofline_of(a, l_sts[-1], l_fill, cells_local, cnum, sharded or n == cfg.get("n_full"))
             block[name] = {"options": dict(opts), "value": round(cells_total * l_steps / l_elapsed / 1e9, 3), "unit": "GCUPS",
                            "steps": l_steps, "ms_per_step": round(l_elapsed / l_steps * 1e3, 4), "dtype": l_dtype,
                            "n_rescored": int(l_sts[-1]["n_rescored"]), "plan": plan_of(l_sts[-1]), "roofline": l_roof,

@@ -67,7 +67,8 @@
 #endif
 // The (K, wave budget) instantiations of the lane-group kernels; the position in this list is the variant index.
 #ifdef SWG_PROBE_VARIANT // (ISA experiments on one instantiation: tools/probe_isa.sh)
-#define SWG_DIAG_VARIANTS(X) X(SWG_PROBE_VARIANT)
+#define SWG_APPLY(X, ...) X(__VA_ARGS__)
+#define SWG_DIAG_VARIANTS(X) SWG_APPLY(X, SWG_PROBE_VARIANT)
 #else
 #define SWG_DIAG_VARIANTS(X)                                                                                          \
     X(24, 16) X(12, 16) X(8, 16) X(16, 16) X(32, 12) X(6, 16) X(10, 16) X(20, 16) X(28, 12) X(4, 16) X(14, 16) X(18, 16) \
@@ -960,6 +961,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     uint32_t em_rot[2] = {Z, Z}, eb_rot[2] = {Z, Z};
     uint32_t zero_v = Z; // (F16: the floor operand of the maxima, kept in a register)
     asm volatile("" : "+v"(zero_v));
+    // F16: all ones in a lane whose running best was 32768 or more when its pair ended (looked at once per pair, on the
+    // last row, where the best is being read anyway, instead of on every flagged row: ten instructions fewer per pair and lane)
+    uint32_t wipe_next = 0u;
     uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
     uint32_t nlast = 0u;               // last rows this lane has seen = position of its pair in the group's rings
     // Tokens: T0..T3 are the rows of the block being worked on.  Each is re-loaded with the same row of
@@ -1194,8 +1198,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     if (__builtin_amdgcn_ballot_w64(fw != 0u) != 0ull) cells.wipe(fw);
                 } else if (F16) {
                     // (two rows at 65504 clear any state below 32768; a lane that got beyond is wiped by hand)
-                    const uint32_t fi = fm & cells.best_is_huge();
-                    if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) cells.wipe(fi);
+                    const uint32_t fi = fm & wipe_next;
+                    if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) {
+                        cells.wipe(fi);
+                        wipe_next &= ~fi;
+                    }
                     cells.best = (cells.best & ~fm) | (Z & fm);
                     go_v = (go_v & ~fm) | (SWG_F16_BIG & fm);
                     ge_v = (ge_v & ~fm) | (SWG_F16_BIG & fm);
@@ -1227,6 +1234,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     // is the last of the group to get here and finishes the pair
                     uint32_t *st = record();
                     const uint32_t at = nlast & (SWG_DYN_RING - 1u);
+                    if (F16) wipe_next = cells.best_is_huge();
                     const uint32_t c = cells.best ^ (F16 ? 0u : Z);
                     const uint32_t cx = F16 ? f16_key(c & 0xFFFFu) : c & 0xFFFFu, cy = F16 ? f16_key(c >> 16) : c >> 16;
                     __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1758,6 +1766,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
     uint32_t em_rot[2] = {Z, Z}, eb_rot[2] = {Z, Z}; // (written only by the DPP moves: the leader keeps score 0, see swg_diag_dyn_kernel)
     uint32_t zero_v = Z;
     asm volatile("" : "+v"(zero_v));
+    uint32_t wipe_next = 0u; // (see swg_diag_dyn_kernel)
     uint32_t go_v = p.go, ge_v = p.ge;
     uint32_t nlast = 0u;
     // v_perm selector of the leader: residue byte of X (.. 00) or Y (.. 01), zero, flags byte, zero; the blocks in
@@ -1876,8 +1885,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
             if (special) {
                 uint32_t fm = 0u - ((tok >> 16) & 1u);
                 asm volatile("" : "+v"(fm)); // (keeps this a branch)
-                const uint32_t fi = fm & cells.best_is_huge();
-                if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) cells.wipe(fi);
+                const uint32_t fi = fm & wipe_next;
+                if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) {
+                    cells.wipe(fi);
+                    wipe_next &= ~fi;
+                }
                 cells.best = (cells.best & ~fm) | (Z & fm);
                 go_v = (go_v & ~fm) | (SWG_F16_BIG & fm);
                 ge_v = (ge_v & ~fm) | (SWG_F16_BIG & fm);
@@ -1889,6 +1901,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
                 if (tok & SWG_TOK_LAST) {
                     uint32_t *st = record();
                     const uint32_t at = nlast & (SWG_DYN_RING - 1u);
+                    wipe_next = cells.best_is_huge();
                     __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, f16_key(cells.best & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, f16_key(cells.best >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (tail) {

@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_c$CFG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-host-inclusive --no-verify"
+ARGS="--config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-host-inclusive --no-verify $EXTRA"   # EXTRA: e.g. "--nseq 10000000" for config 4 whole
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
