@@ -22,8 +22,9 @@
 //    swg_diag_kernel is the same engine with a fixed stream of pairs per group (option dynamic = 0).
 //
 //  * The same engine in 32-bit cells (swg_diag32q_kernel): one sequence per group, used when scores
-//    may pass 16 bits, for re-scoring flagged sequences and when forced; and the exact three-state
-//    recurrence for positive gap scores (swg_diag32_kernel).
+//    may pass 16 bits, for re-scoring flagged sequences and when forced; with a second cell type, the exact
+//    three-state recurrence, for gap scores of any sign (swg_diag32_kernel, the older bin-based form of that,
+//    is left for work_queue = 0 and databases beyond 32-bit edge indices).
 //
 //  * The systolic fill (swg_fill_kernel): a wavefront owns 128 whole sequences of a bin and W waves
 //    of a workgroup split the query's columns, edges crossing through an LDS ring.  It needs no
@@ -38,7 +39,9 @@
 //    costs one ds_read_b64 per 8 cells and its address one SDWA xor per row.
 //
 //  * No MFMA: the recurrence is integer max/add with a loop-carried dependency.  The bound is VALU
-//    issue: 10 packed instructions per 2 cells.
+//    issue: 10 packed instructions per 2 cells on the int16 cells, 8.5 on the packed-f16 cells that gfx950's
+//    three-operand maximum allows (CellsDiag FORM 2: exact below a score of 4096, anything above flagged and run
+//    again), 7.5 with two queries of a batch per lane (swg_diag_qq_kernel).
 //
 // int16 fast path (gap_open <= 0 and gap_extend <= 0, the normal case): with
 // M = max(H,A,B) the recurrence collapses to
