@@ -60,6 +60,12 @@ template <int OP> __device__ __forceinline__ void op16(uint32_t (&x)[16], uint32
 #define A_BFI(i) A_G(i, "v_bfi_b32 %0, %2, %0, %1")
 #define A_ANDOR(i) A_G(i, "v_and_or_b32 %0, %0, %1, %2")
 #define A_LSHLOR(i) A_G(i, "v_lshl_or_b32 %0, %0, 16, %1")
+// round 3: the f16 cells' instructions (gfx950 three-operand packed maximum), alone and mixed as the cell mixes them
+#define A_PKMAX3F16(i) A_G(i, "v_pk_maximum3_f16 %0, %0, %1, %2")
+#define A_PKMIN3F16(i) A_G(i, "v_pk_minimum3_f16 %0, %0, %1, %2")
+#define A_MIXF16A(i) A_G(i, "v_pk_add_f16 %0, %0, %1\n\tv_pk_maximum3_f16 %0, %0, %1, %2")
+#define A_MIXF16B(i) A_G(i, "v_perm_b32 %0, %0, %1, %2\n\tv_pk_maximum3_f16 %0, %0, %1, %2")
+#define A_MIXF16C(i) A_G(i, "v_pk_maximum3_f16 %0, %0, %1, %2\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
     if constexpr (OP == 0) { OPS16(A_PKADD) }
     if constexpr (OP == 1) { OPS16(A_PKSUB) }
     if constexpr (OP == 2) { OPS16(A_PKMAX) }
@@ -106,6 +112,11 @@ template <int OP> __device__ __forceinline__ void op16(uint32_t (&x)[16], uint32
     if constexpr (OP == 123) { OPS16(A_BFI) }
     if constexpr (OP == 124) { OPS16(A_ANDOR) }
     if constexpr (OP == 125) { OPS16(A_LSHLOR) }
+    if constexpr (OP == 130) { OPS16(A_PKMAX3F16) }
+    if constexpr (OP == 131) { OPS16(A_PKMIN3F16) }
+    if constexpr (OP == 132) { OPS16(A_MIXF16A) }
+    if constexpr (OP == 133) { OPS16(A_MIXF16B) }
+    if constexpr (OP == 134) { OPS16(A_MIXF16C) }
 }
 
 template <int OP> __global__ void k(uint32_t *out, unsigned long long *cyc, int rep)
@@ -165,13 +176,24 @@ int main(int argc, char **argv)
 {
     if (argc > 1) g_blocks = atoi(argv[1]);
     if (argc > 2) g_lds = atoi(argv[2]) * 1024;  // LDS per block: 96 KB = 1 block per CU, 64 KB = 2, 32 KB = 4
-    if (argc > 3) g_quick = atoi(argv[3]);       // 1: packed ops only
+    if (argc > 3) g_quick = atoi(argv[3]);       // 1: packed int16 ops only; 2: those and the f16 cells' instructions
     printf("blocks=%d lds=%d\n", g_blocks, g_lds);
     run<0>("v_pk_add_i16 clamp");
     run<1>("v_pk_sub_u16 clamp");
     run<2>("v_pk_max_i16");
     run<3>("v_pk_add_u16");
     run<15>("v_pk_max_i16 (sgpr lit)");
+    if (g_quick == 2) { // the f16 cells' instructions only (round 3); the MIX rows issue TWO instructions per slot: halve their figures
+        run<111>("v_pk_add_f16");
+        run<110>("v_pk_max_f16");
+        run<130>("v_pk_maximum3_f16");
+        run<131>("v_pk_minimum3_f16");
+        run<4>("v_perm_b32");
+        run<132>("MIX pk_add_f16 + pk_maximum3 (x2)");
+        run<133>("MIX v_perm + pk_maximum3 (x2)");
+        run<134>("MIX pk_maximum3 + mov_dpp (x2)");
+        return 0;
+    }
     if (g_quick) return 0;
     run<4>("v_perm_b32");
     run<5>("v_add_u32");
