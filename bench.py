@@ -416,7 +416,7 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     # (counters are collected per configuration and cell form as bench.py --config C runs it; a leg without a
     # measurement of its own gets null rather than a neighbour's figure)
     table, source = _traffic_table(a.traffic_json)
-    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {2: "_f16"}.get(form, "") if q16 else "_int32")
+    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {1: "_wide", 2: "_f16"}.get(form, "") if q16 else "_int32")
     traffic = table.get(key, {}).get("hbm_bytes_per_launch")
     # The binding roof is VALU issue, reported beside the (by construction tiny) HBM fraction: one wave64 packed
     # instruction per SIMD every 4 cycles (16 lanes per cycle) at 2.4 GHz.  Instructions per cell: 5 for the packed

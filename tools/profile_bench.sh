@@ -2,7 +2,7 @@
 # counters in their own passes (MI355X_MICROARCH.md, HBM / rocprofv3 PMC sections), then SQ / LDS counters.
 #   bash tools/profile_bench.sh <config> [steps] [traffic key]  -> gpurun_out/prof_c<config>/{summary,traffic}.json
 # The traffic key is what bench.py looks up in profiles/traffic.json: config<C>_f16 for the packed-f16 cells (the default
-# for configs 2-4), config<C> for the int16 cells, config<C>_int32.  FETCH_SIZE is doubled: on gfx950 it reports half the
+# for configs 2-4), config<C>_wide for the wide int16 form (config 5), config<C> for the int16 cells, config<C>_int32.  FETCH_SIZE is doubled: on gfx950 it reports half the
 # bytes fetched, for every load shape of these kernels (tools/fetch_probe.hip, profiles/r03_fetch_size_probe.txt).
 CFG=${1:-3}
 STEPS=${2:-${STEPS:-20}}
