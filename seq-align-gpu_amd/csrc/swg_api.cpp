@@ -2619,15 +2619,28 @@ static int fill_batches16_device(swg_ctx *ctx, const swg_batch16 *batches, size_
     memcpy(h_order, db->order.data(), n_slots * 4);
     t_ms[0] = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
     const clk::time_point t1 = clk::now();
+    hipStream_t s = ctx->stream;
     {
-        const long long nb = (long long)n_batches;
-#pragma omp parallel for schedule(dynamic, 32) num_threads(swg_host_threads())
-        for (long long b = 0; b < nb; ++b) memcpy(C.h_stage + stage_off[b], batches[b].db_idx_t, (size_t)batches[b].max_len * 16u);
+        // the batches into pinned staging by all cores, in runs of about 4 MB (in staging order): a run's transfer is
+        // queued as soon as it is copied, so the upload of one run overlaps the copy of the next
+        size_t k0 = 0;
+        while (k0 < n_batches) {
+            size_t k1 = k0;
+            uint64_t bytes = 0;
+            while (k1 < n_batches && bytes < (4u << 20)) bytes += (uint64_t)batches[bo[k1++]].max_len * 16u;
+            const long long lo = (long long)k0, hi = (long long)k1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(swg_host_threads())
+            for (long long k = lo; k < hi; ++k) {
+                const swg_batch16 &bt = batches[bo[k]];
+                memcpy(C.h_stage + stage_off[bo[k]], bt.db_idx_t, (size_t)bt.max_len * 16u);
+            }
+            const uint64_t from = stage_off[bo[k0]];
+            HIP_TRY(ctx, hipMemcpyAsync(C.d_stage + from, C.h_stage + from, bytes, hipMemcpyHostToDevice, s));
+            k0 = k1;
+        }
     }
     t_ms[1] = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
     const clk::time_point t2 = clk::now();
-    hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(C.d_stage, C.h_stage, stage_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(C.d_pair_src, pair_src, n_pairs * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(C.d_pair_len, pair_len, n_pairs * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(T.d_pair_off, T.pair_blocks_prefix.data(), (n_pairs + 1) * 4, hipMemcpyHostToDevice, s));
