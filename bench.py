@@ -140,12 +140,21 @@ class Env:
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        torch.cuda.set_device(self.local_rank)
+        # SWG_BENCH_BACKEND=gloo (rehearsal only): the ranks' collectives go through gloo on host tensors and the ranks
+        # share the GPUs that are there (rank r on device r mod the device count) -- N ranks of the real sharded
+        # search on a one-GPU box, everything but RCCL itself (which the one-rank rehearsal covers)
+        self.backend = os.environ.get("SWG_BENCH_BACKEND", "nccl")
+        self.coll_device = "cuda" if self.backend == "nccl" else "cpu"
+        self.device_index = self.local_rank if self.backend == "nccl" else self.local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(self.device_index)
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                    device_id=torch.device("cuda", self.local_rank))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         lib_path = os.path.join(ROOT, "seq-align-gpu_amd", "libswg.so")
         if not os.path.exists(lib_path):
             if self.rank == 0:
@@ -167,7 +176,7 @@ class Env:
 
 def make_context(env, q, sc):
     a = env.args
-    ctx = env.swg.Context(env.local_rank)
+    ctx = env.swg.Context(env.device_index)
     ctx.set_scoring(sc, a.gapopen, a.gapextend)
     ctx.set_query(q)
     ctx.set_option("cols_per_wave", a.cols)
@@ -240,7 +249,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
     # for this database (and with --autotune times the best-ranked plans on this device)
     ctx.search(db, want_scores=False, k=K)
 
-    merger = TopKMerger(swg, K, env.rank, env.world, "cuda") if env.use_dist else None
+    merger = TopKMerger(swg, K, env.rank, env.world, env.coll_device) if env.use_dist else None
     # Steps are software-pipelined two deep: search i+1 is queued on the GPU before the host finishes
     # search i (top-K read-out, and for N > 1 the all-reduce merge).  The library runs a search's
     # top-K kernels and read-out on a stream of their own, beside the start of the next fill; deeper
@@ -287,12 +296,12 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
     torch, dist = env.torch, env.dist
     per_rank = None
     if env.use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=env.coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank's own timed region and mean fill time, so that an uneven deal of the bins would show
-        mine = torch.tensor([elapsed_own * 1e3 / steps, float(np.mean(fill_ms)), float(db.residues)], dtype=torch.float64, device="cuda")
-        allr = [torch.zeros(3, dtype=torch.float64, device="cuda") for _ in range(env.world)]
+        mine = torch.tensor([elapsed_own * 1e3 / steps, float(np.mean(fill_ms)), float(db.residues)], dtype=torch.float64, device=env.coll_device)
+        allr = [torch.zeros(3, dtype=torch.float64, device=env.coll_device) for _ in range(env.world)]
         dist.all_gather(allr, mine)
         allr = np.array([r.cpu().numpy() for r in allr])
         per_rank = {"ms_per_step": {"min": round(float(allr[:, 0].min()), 4), "max": round(float(allr[:, 0].max()), 4)},
@@ -302,7 +311,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
     if sharded:
         cells_total = float(lq) * float(residues_total)          # ONE database, whatever the number of ranks
     elif env.use_dist:
-        c = torch.tensor([float(lq) * residues], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(lq) * residues], dtype=torch.float64, device=env.coll_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         cells_total = float(c.item())
     else:
@@ -498,13 +507,13 @@ def verify_topk(env, ctx, db, q, sc, flat, off, index, K, merger, timed_hits):
         mine = np.zeros(K, dtype=np.uint64)
         mine[:len(keys)] = keys
         merged = merger.merge_keys(mine)                          # the path the timed steps take
-        gathered = [torch.zeros(K, dtype=torch.int64, device="cuda") for _ in range(env.world)]
-        dist.all_gather(gathered, torch.from_numpy(mine.view(np.int64)).cuda())
+        gathered = [torch.zeros(K, dtype=torch.int64, device=env.coll_device) for _ in range(env.world)]
+        dist.all_gather(gathered, torch.from_numpy(mine.view(np.int64)).to(env.coll_device))
         allk = np.concatenate([g.cpu().numpy().view(np.uint64) for g in gathered])
         allk = np.sort(allk[allk != 0])[::-1][:K]
         plain = [swg.key_hit(int(k)) for k in allk]
         ok_c = merged == plain and (timed_hits is None or list(timed_hits) == plain)
-        flag = torch.tensor([1 if (ok and ok_c) else 0], dtype=torch.int64, device="cuda")
+        flag = torch.tensor([1 if (ok and ok_c) else 0], dtype=torch.int64, device=env.coll_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         res.update({"merge_equals_gather_and_sort": bool(ok_c), "all_ranks_ok": bool(int(flag.item()) == 1),
                     "best": plain[:3]})
@@ -586,6 +595,25 @@ def cpu_model():
     return "unknown"
 
 
+def available_cpus():
+    """CPUs this process may use, whatever OMP_NUM_THREADS says (a launcher sets it to 1 for its ranks): the affinity
+    mask, capped by a cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(swg, q, flat, off, sc, lq):
     """The reference's own fill (oracle/_ref: its alignment.c compiled from its sources,
     dispatched as its driver does) on this host's cores, over a bounded sample of the
@@ -611,8 +639,10 @@ def cpu_baseline(swg, q, flat, off, sc, lq):
         # The reference takes omp_get_max_threads() threads (src/alignment_cmdline.c:341-347): all
         # hardware threads of the host.  This process may own fewer CPUs (cgroup quota, cpuset), so it is
         # timed with that many threads too and the better rate is the baseline.
-        hw = int(orc.rlib().swref_max_threads())
-        share = int(swg.lib.swg_host_threads())
+        # (under a launcher OMP_NUM_THREADS is 1 for every rank; the baseline runs on rank 0 alone, outside the timed
+        # region, while the other ranks wait: it takes the CPUs the process may use, not the launcher's setting)
+        share = max(int(swg.lib.swg_host_threads()), available_cpus())
+        hw = max(int(orc.rlib().swref_max_threads()), share)
         orc.ref_batches(q, batches[:min(len(batches), 64)], table, -2, -1)      # warm the pages
         runs = {}
         for t in sorted({hw, min(hw, share)}):
