@@ -1020,11 +1020,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         else __builtin_amdgcn_s_setprio(3);
     };
 
-    // The main loop exists twice, for groups of 16 lanes (edges handed over by row_shr) and for wider ones
-    // (wave_shr and a select at lane 32): a run-time test of G inside the row makes the register allocator's
-    // job harder than it is.
-    auto main_loop = [&](auto g16_tag) {
-    constexpr bool G16 = decltype(g16_tag)::value;
+    // The main loop exists three times, for groups of 16 lanes (edges handed over by row_shr), of 32 (wave_shr and a
+    // select at lane 32) and of 64 (wave_shr alone): a run-time test of G inside the row makes the register allocator's
+    // job harder than it is, and a 64-lane group -- the long class, config 5's passes -- paid for the 32-lane select
+    // (three v_cndmask per row) without needing it.
+    auto main_loop = [&](auto gw_tag) {
+    constexpr int GW = decltype(gw_tag)::value; // lanes per group, a constant inside the loop
+    constexpr bool G16 = GW == 16;
     for (;;) {
         if (blocks == next_event) {
             // some pair has run out (or this is the start): its leader takes the next one
@@ -1141,7 +1143,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 lb = quad_bcast(ec.y, r);
             }
             uint32_t em, eb;
-            const int Gs = G16 ? 16 : opaque_uniform(G);
+            constexpr int Gs = GW;
             constexpr bool KEEP = F16 && !EDGES; // (see em_rot)
             if (G16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
@@ -1276,8 +1278,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         if (!hot && (blocks & (SWG_DYN_TURN_EVERY - 1u)) == 0u) take_turn();
     }
     };
-    if (G == 16) main_loop(std::true_type());
-    else main_loop(std::false_type());
+    if (G == 16) main_loop(std::integral_constant<int, 16>());
+    else if (G == 32) main_loop(std::integral_constant<int, 32>());
+    else main_loop(std::integral_constant<int, 64>());
     if (p.stamps && lane == 0) atomicMax(p.stamps + 1, (unsigned long long)wall_clock64()); // latest end
     if (p.trace && lane == 0) {
         uint64_t *t = p.trace + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * W + w) * 4u;
@@ -1489,8 +1492,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     };
 
     // (two loops, for 16-lane groups and for wider ones: see swg_diag_qq_kernel)
-    auto main_loop = [&](auto g16_tag) {
-    constexpr bool G16 = decltype(g16_tag)::value;
+    auto main_loop = [&](auto gw_tag) {
+    constexpr int GW = decltype(gw_tag)::value; // lanes per group, a constant inside the loop
+    constexpr bool G16 = GW == 16;
     for (;;) {
         if (blocks == next_event) {
             // some sequence has run out (or this is the start): its leader takes the next one
@@ -1575,7 +1579,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
                 fresh_ridx = rb_cur != SWG_DYN_NONE ? rb_cur + 2u * (uint32_t)r : SWG_DYN_NONE;
             }
             int em, eb, ed = 0;
-            const int Gs = G16 ? 16 : opaque_uniform(G);
+            constexpr int Gs = GW;
             if (G16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
                 em = (int)(EDGES ? dpp_keep<DPP_ROW_SHR1>(lm, (uint32_t)m_out) : dpp_zero<DPP_ROW_SHR1>((uint32_t)m_out));
@@ -1651,8 +1655,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
         if (!hot) take_turn();
     }
     };
-    if (G == 16) main_loop(std::true_type());
-    else main_loop(std::false_type());
+    if (G == 16) main_loop(std::integral_constant<int, 16>());
+    else if (G == 32) main_loop(std::integral_constant<int, 32>());
+    else main_loop(std::integral_constant<int, 64>());
 }
 
 // ---------------------------------------------------------------------------
@@ -1802,8 +1807,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
     // (the loop exists twice, for 16-lane groups and for wider ones, chosen once per launch: a run-time test of G inside the
     // row makes the compiler issue BOTH hand-overs on every row -- three wave_shr moves and three selects, then, for 16
     // lanes, three row_shr moves and five copies -- eleven instructions per row too many)
-    auto main_loop = [&](auto g16_tag) {
-    constexpr bool G16 = decltype(g16_tag)::value;
+    auto main_loop = [&](auto gw_tag) {
+    constexpr int GW = decltype(gw_tag)::value; // lanes per group, a constant inside the loop
+    constexpr bool G16 = GW == 16;
     for (;;) {
         if (blocks == next_event) {
             __builtin_amdgcn_s_setprio(3);
@@ -1861,7 +1867,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
             const uint32_t raw = r == 0 ? T0 : r == 1 ? T1 : r == 2 ? T2 : T3;
             const uint32_t fresh = __builtin_amdgcn_perm(raw, raw, pick_cur);
             uint32_t em, eb;
-            const int Gs = G16 ? 16 : opaque_uniform(G);
+            constexpr int Gs = GW;
             if (G16) {
                 tok = dpp_keep<DPP_ROW_SHR1>(fresh, tok);
                 em = em_rot[r & 1] = dpp_keep<DPP_ROW_SHR1>(em_rot[r & 1], m_out);
@@ -1927,8 +1933,9 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
         if (!hot) take_turn();
     }
     };
-    if (G == 16) main_loop(std::true_type());
-    else main_loop(std::false_type());
+    if (G == 16) main_loop(std::integral_constant<int, 16>());
+    else if (G == 32) main_loop(std::integral_constant<int, 32>());
+    else main_loop(std::integral_constant<int, 64>());
 }
 
 #if SWG_HAS_PART(0)
