@@ -253,3 +253,9 @@ hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slot
 hipError_t swg_launch_topk(const int32_t *d_scores, const uint32_t *d_order, uint32_t n_slots, uint32_t k,
                            uint32_t *d_hist, uint32_t *d_thr, uint64_t *d_cand, uint32_t cap, uint32_t *d_count,
                            hipStream_t stream);
+// ... and for the n_queries score rows of a batch (swg_search_multi) at once: d_hist[n_queries][4096],
+// d_meta[n_queries][4] = {threshold, status, candidate count, -}, d_cand[n_queries][cap]
+#define SWG_TOPK_MULTI_CAP 1024u
+hipError_t swg_launch_topk_multi(const int32_t *d_scores, uint64_t score_stride, const uint32_t *d_order, uint32_t n_slots,
+                                 uint32_t n_queries, uint32_t k, uint32_t *d_hist, uint32_t *d_meta, uint64_t *d_cand, uint32_t cap,
+                                 hipStream_t stream);

@@ -2337,8 +2337,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32_kernel(const SwgFillPara
 // to fall back to reading all scores.
 #define SWG_TOPK_BINS 4096
 
-__global__ void swg_topk_hist_kernel(const int32_t *scores, const uint32_t *order, uint32_t n, uint32_t *hist)
+// (blockIdx.y = query of a batch, swg_search_multi: its score row at scores + y * score_stride, its histogram at
+// hist + y * SWG_TOPK_BINS, its threshold / status / count words at meta + y * 4 and its candidates at cand + y * cap;
+// a single search is a grid of one row with its own pointers)
+__global__ void swg_topk_hist_kernel(const int32_t *scores, const uint32_t *order, uint32_t n, uint32_t *hist, uint64_t score_stride)
 {
+    scores += (size_t)blockIdx.y * score_stride;
+    hist += (size_t)blockIdx.y * SWG_TOPK_BINS;
     // These few wavefronts run BESIDE the next search's fill (their own stream): at the default priority the
     // persistent fill wavefronts starve them for milliseconds; at the top one they are done in microseconds.
     __builtin_amdgcn_s_setprio(3);
@@ -2365,6 +2370,8 @@ __global__ void swg_topk_hist_kernel(const int32_t *scores, const uint32_t *orde
 __global__ __launch_bounds__(SWG_TOPK_THR_THREADS) __attribute__((amdgpu_num_vgpr(8))) void
 swg_topk_threshold_kernel(const uint32_t *hist, uint32_t k, uint32_t cap, uint32_t *out)
 {
+    hist += (size_t)blockIdx.x * SWG_TOPK_BINS; // (one block per query of a batch)
+    out += (size_t)blockIdx.x * 4u;
     __builtin_amdgcn_s_setprio(3);
     constexpr int PER = SWG_TOPK_BINS / SWG_TOPK_THR_THREADS;
     __shared__ uint32_t part[SWG_TOPK_THR_THREADS];
@@ -2406,8 +2413,12 @@ swg_topk_threshold_kernel(const uint32_t *hist, uint32_t k, uint32_t cap, uint32
 }
 
 __global__ void swg_topk_compact_kernel(const int32_t *scores, const uint32_t *order, uint32_t n,
-                                        const uint32_t *thr, uint64_t *cand, uint32_t cap, uint32_t *count)
+                                        const uint32_t *thr, uint64_t *cand, uint32_t cap, uint32_t *count, uint64_t score_stride)
 {
+    scores += (size_t)blockIdx.y * score_stride;
+    thr += (size_t)blockIdx.y * 4u;
+    count += (size_t)blockIdx.y * 4u;
+    cand += (size_t)blockIdx.y * cap;
     // These few wavefronts run BESIDE the next search's fill (their own stream): at the default priority the
     // persistent fill wavefronts starve them for milliseconds; at the top one they are done in microseconds.
     __builtin_amdgcn_s_setprio(3);
@@ -2430,10 +2441,30 @@ hipError_t swg_launch_topk(const int32_t *d_scores, const uint32_t *d_order, uin
     if (e != hipSuccess) return e;
     const int blocks = (int)((n_slots + 255) / 256 < 512 ? (n_slots + 255) / 256 : 512);
     hipLaunchKernelGGL(swg_topk_hist_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, d_scores, d_order,
-                       n_slots, d_hist);
+                       n_slots, d_hist, (uint64_t)0);
     hipLaunchKernelGGL(swg_topk_threshold_kernel, dim3(1), dim3(SWG_TOPK_THR_THREADS), 0, stream, d_hist, k, cap, d_thr);
     hipLaunchKernelGGL(swg_topk_compact_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, d_scores,
-                       d_order, n_slots, d_thr, d_cand, cap, d_count);
+                       d_order, n_slots, d_thr, d_cand, cap, d_count, (uint64_t)0);
+    return hipGetLastError();
+}
+
+// The same for the n_queries score rows of a batch (row y at d_scores + y * score_stride) in three launches:
+// d_hist[n_queries][4096], d_meta[n_queries][4] = {threshold, status (0 ok / 1 fall back), candidates, -},
+// d_cand[n_queries][cap].
+hipError_t swg_launch_topk_multi(const int32_t *d_scores, uint64_t score_stride, const uint32_t *d_order, uint32_t n_slots,
+                                 uint32_t n_queries, uint32_t k, uint32_t *d_hist, uint32_t *d_meta, uint64_t *d_cand, uint32_t cap,
+                                 hipStream_t stream)
+{
+    if (n_queries == 0 || n_queries > 65535) return n_queries ? hipErrorInvalidValue : hipSuccess;
+    hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)n_queries * SWG_TOPK_BINS * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_meta, 0, (size_t)n_queries * 16, stream)) != hipSuccess) return e;
+    const int blocks = (int)((n_slots + 255) / 256 < 64 ? (n_slots + 255) / 256 : 64);
+    hipLaunchKernelGGL(swg_topk_hist_kernel, dim3(blocks > 0 ? blocks : 1, n_queries), dim3(256), 0, stream, d_scores, d_order,
+                       n_slots, d_hist, score_stride);
+    hipLaunchKernelGGL(swg_topk_threshold_kernel, dim3(n_queries), dim3(SWG_TOPK_THR_THREADS), 0, stream, d_hist, k, cap, d_meta);
+    hipLaunchKernelGGL(swg_topk_compact_kernel, dim3((n_slots + 255) / 256, n_queries), dim3(256), 0, stream, d_scores, d_order,
+                       n_slots, d_meta, d_cand, cap, d_meta + 2, score_stride);
     return hipGetLastError();
 }
 

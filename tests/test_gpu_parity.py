@@ -1097,6 +1097,13 @@ def test_many_queries_cell_forms(swg, ctx, orc, opts, form):
         for i, q in enumerate(qs):
             want = orc.score_db(q, flat, off, tab, -3, -1)
             assert np.array_equal(got[i], want) and hits[i] == orc.topk(want, 4), (opts, n, i)
+        # hits only: the batch's top-K is selected on the device (three launches for all queries) -- the same lists,
+        # also where many sequences tie at the k-th score (k = 300 reaches deep into a 1-residue query's ties)
+        for k in (1, 4, 300):
+            none, hits_dev, _ = ctx.search_multi(db, qs, k=k, want_scores=False)
+            assert none is None
+            for i in range(len(qs)):
+                assert hits_dev[i] == orc.topk(got[i], k), (opts, n, i, k)
         db.close()
     _reset_options(ctx)
 

@@ -27,3 +27,7 @@ for nq in (2, 8, 32):
     ctx.set_query(qs[-1])
     ref, _, _ = ctx.search(db)
     assert np.array_equal(got[-1], ref)
+    t0 = time.perf_counter()
+    _, hits, st = ctx.search_multi(db, qs, k=100, want_scores=False)
+    wall = time.perf_counter() - t0
+    print("   top-100 only (selected on the device): fill %.3f ms, wall %.1f ms" % (st["fill_ms"], wall * 1e3))
