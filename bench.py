@@ -391,7 +391,9 @@ def plan_of(last):
             "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
             "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
             "cells": {0: "packed int16", 1: "packed int16, wide form (to 65535)",
-                      2: "packed f16, three-operand maxima (exact below 4096; above: int32 re-score)"}.get(last["cell_form"])
+                      2: "packed f16, three-operand maxima (exact below 4096; above: int32 re-score)",
+                      4: "packed f16 for sequences under %d rows, wide int16 form for the longer ones "
+                         "(what the f16 cells flag all the same: the wide form again)" % last["split_rows"]}.get(last["cell_form"])
                      if last["path_bits"] == 16 else "int32",
             "streams": last["streams"], "long_pairs": last["long_pairs"],
             "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],
@@ -425,14 +427,35 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     # (counters are collected per configuration and cell form as bench.py --config C runs it; a leg without a
     # measurement of its own gets null rather than a neighbour's figure)
     table, source = _traffic_table(a.traffic_json)
-    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {1: "_wide", 2: "_f16"}.get(form, "") if q16 else "_int32")
+    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {1: "_wide", 2: "_f16", 4: "_split"}.get(form, "") if q16 else "_int32")
     traffic = table.get(key, {}).get("hbm_bytes_per_launch")
     # The binding roof is VALU issue, reported beside the (by construction tiny) HBM fraction: one wave64 packed
     # instruction per SIMD every 4 cycles (16 lanes per cycle) at 2.4 GHz.  Instructions per cell: 5 for the packed
     # int16 cells (10 per column pair), 4.25 for the packed f16 cells (8.5), 8 for the int32 work-queue kernel,
     # 12 for the term-by-term int32 kernels.  An isolated stream of packed instructions measures 4.4-4.56 cycles
     # with 4 waves per SIMD (tools/valu_rate.hip); the fill kernels get to 4.05.
-    if q16:
+    split = None
+    if q16 and form == 4:
+        # both 16-bit forms in one search: half of the launches ran the long sequences on the wide form, the other
+        # half -- the dominant kernel, which this object describes -- the rest on the f16 cells; the library times
+        # the two parts apart (swg_stats.fill_f16_ms) and says how many cells each took
+        share = float(last["fill_f16_ms"]) / max(1e-9, float(last["fill_ms"]))
+        cells_f16 = int(last["cells_f16"])
+        wide_ms, wide_cells = step_fill_ms * (1.0 - share), cells_local - cells_f16
+        n_f16 = max(1, int(last["fill_f16_launches"]))
+        n_wide = max(1, launches - n_f16)
+        split = {"kernel": "swg_diag_dyn_kernel<K=%d,wide>" % last["cols_per_wave"], "launches_per_step": n_wide,
+                 "kernel_ms": round(wide_ms / n_wide, 4), "cells_share": round(wide_cells / max(1, cells_local), 4),
+                 "kernel_gcups": round(wide_cells / (wide_ms * 1e-3) / 1e9, 2), "instr_per_cell": 5.0}
+        bytes_alg = int(int(last["bytes_alg"]) * (cells_f16 / max(1, cells_local))) // n_f16
+        step_fill_ms *= share
+        cells_local = cells_f16
+        launches = n_f16
+        k_ms = step_fill_ms / launches
+        achieved = bytes_alg / (k_ms * 1e-3) / 1e9
+        ops_per_cell = 4.25
+        kname = "swg_diag_dyn_kernel<K=%d,f16>" % last["cols_per_wave"]
+    elif q16:
         ops_per_cell = 4.25 if form == 2 else 5.0
         kname = ("swg_diag_dyn_kernel<K=%d,%s>" if last["work_queue"] else "swg_diag_kernel<K=%d,%s>") % (
             last["cols_per_wave"], {0: "int16", 1: "wide", 2: "f16"}[form])
@@ -458,7 +481,12 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
                          "peak_gcups_issue": round(peak_issue, 1),
                          "frac_of_issue_peak": round(kernel_gcups / peak_issue, 4)},
     }
-    dtype = ("f16" if form == 2 else "int16") if last["path_bits"] == 16 else "int32"
+    if split is not None:
+        split["peak_gcups_issue"] = round(simds * 64 / 4.0 * 2.4e9 / split["instr_per_cell"] / 1e9, 1)
+        split["frac_of_issue_peak"] = round(split["kernel_gcups"] / split["peak_gcups_issue"], 4)
+        roofline["binding_roof"]["cells_share"] = round(1.0 - split["cells_share"], 4)
+        roofline["binding_roof"]["other_kernel"] = split
+    dtype = ("f16" if form == 2 else "f16+int16" if form == 4 else "int16") if last["path_bits"] == 16 else "int32"
     return roofline, dtype
 
 

@@ -65,7 +65,8 @@ typedef struct swg_stats {
     uint64_t cells;         /* lq * sum(len_i): real cells, what GCUPS counts */
     uint64_t cells_padded;  /* cells actually computed (bin + strip padding) */
     uint64_t bytes_alg;     /* algorithmic HBM bytes of the fill */
-    uint64_t n_rescored;    /* sequences re-scored in int32 after reaching the 16-bit cells' ceiling */
+    uint64_t n_rescored;    /* sequences that reached the ceiling of the cells they ran on and were run again on wider
+                             * ones (cell_form 2: those the f16 cells flagged; 4: those plus the wide form's) */
     double fill_ms;         /* 16-bit fill kernel (or the int32 fill when forced) */
     double rescore_ms;      /* overflow collection + int32 re-score */
     double topk_ms;         /* device top-K selection */
@@ -95,8 +96,15 @@ typedef struct swg_stats {
     /* the cells the 16-bit fill ran on: 0 packed int16 (scores to 32767), 1 the wide int16 form (to 65535),
      * 2 packed f16 with gfx950's three-operand maxima (exact below 4096; a sequence that reaches it is
      * flagged and re-scored in int32 like an int16 saturation), 3 (swg_search_multi only) the f16 cells with two
-     * QUERIES per lane against one sequence instead of two sequences against one query */
+     * QUERIES per lane against one sequence instead of two sequences against one query, 4 both of the 16-bit
+     * forms in one search: a query long enough to score beyond 32767 runs the sequences that could reach the f16
+     * cells' ceiling -- those of split_rows rows or more -- on the wide form and everything shorter on the f16
+     * cells (what those flag all the same is run again on the wide form, so the scores are exact either way) */
     int32_t cell_form;
+    int32_t split_rows;     /* cell_form 4: the length from which sequences took the wide form; else 0 */
+    int32_t fill_f16_launches; /* cell_form 4: how many of fill_launches ran the f16 cells; else 0 */
+    double fill_f16_ms;     /* cell_form 4: the part of fill_ms spent on the f16 cells; else 0 */
+    uint64_t cells_f16;     /* cell_form 4: the real cells computed on the f16 cells; else 0 */
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */

@@ -77,6 +77,10 @@ class Stats(C.Structure):
         ("long_streams", C.c_int32), ("work_queue", C.c_int32), ("classes_overlapped", C.c_int32),
         ("fill_launches", C.c_int32),
         ("cell_form", C.c_int32),
+        ("split_rows", C.c_int32),
+        ("fill_f16_launches", C.c_int32),
+        ("fill_f16_ms", C.c_double),
+        ("cells_f16", C.c_uint64),
     ]
 
     def as_dict(self):

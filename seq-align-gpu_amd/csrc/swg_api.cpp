@@ -723,6 +723,11 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
                                      (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols, pl.K, kp, 4,
                                      SWG_LDS_SWIZZLE ? pl.G : 0, diag_class_form(ctx, db, pl) == 2);
         if (rc != SWG_OK) return rc;
+        if (pl.wide && pl.f16_from > 0) { // both forms in this class: the f16 cells' profile of the same geometry
+            rc = ensure_profile_cols(ctx, 7, ncols, 2, (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols,
+                                     pl.K, kp, 4, SWG_LDS_SWIZZLE ? pl.G : 0, 1);
+            if (rc != SWG_OK) return rc;
+        }
     }
     return SWG_OK;
 }
@@ -816,26 +821,45 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                 q.q2_begin = q.q2_end = 0; // (the other class's pairs lie outside a segment)
                 q.queue2 = nullptr;
             }
+            // Both 16-bit forms in one class (pl.f16_from, see swg_search_begin): the pairs before it -- the longest --
+            // take all their passes on the wide form, then the rest theirs on the f16 cells, the same geometry
+            // throughout; ev[5] between the two parts tells their times apart.
+            const uint32_t class_begin = q.q_begin, class_end = q.q_end;
+            const bool split = c == 0 && wk.n_classes == 1 && form == 1 && pl.f16_from > class_begin && pl.f16_from < class_end;
             bool first_launch = true;
-            for (int pass = 0; pass < pl.npass; ++pass) {
-                // one launch per pass: the kernel boundary is what lets any lane group take any pair
-                q.profile = ctx->d_profile[diag_profile_slot(pl, c)] + (size_t)pass * slice;
-                q.edge_in = pass > 0 ? T.d_edge[(pass - 1) & 1] : nullptr;
-                q.edge_out = pass + 1 < pl.npass ? T.d_edge[pass & 1] : nullptr;
-                for (const std::pair<uint32_t, uint32_t> &sg : segs) {
-                    if (!first_launch)
-                        HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, qs));
-                    first_launch = false;
-                    q.q_begin = sg.first;
-                    q.q_end = sg.second;
-                    if (segs.size() > 1) {
-                        q.seg_origin = T.pair_blocks_prefix[sg.first];
-                        q.seg_blocks = T.pair_blocks_prefix[sg.second] - q.seg_origin;
+            int launches = 0, f16_launches = 0;
+            for (int part = 0; part < (split ? 2 : 1); ++part) {
+                const int pform = split && part == 1 ? 2 : form;
+                const uint32_t part_begin = split && part == 1 ? pl.f16_from : class_begin;
+                const uint32_t part_end = split && part == 0 ? pl.f16_from : class_end;
+                const uint8_t *prof = ctx->d_profile[split && part == 1 ? 7 : diag_profile_slot(pl, c)];
+                q.go = pform == 2 ? f16x2_of(-go) : g | (g << 16);
+                q.ge = pform == 2 ? f16x2_of(-ge) : e | (e << 16);
+                if (split && part == 1) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[5], qs));
+                for (int pass = 0; pass < pl.npass; ++pass) {
+                    // one launch per pass: the kernel boundary is what lets any lane group take any pair
+                    q.profile = prof + (size_t)pass * slice;
+                    q.edge_in = pass > 0 ? T.d_edge[(pass - 1) & 1] : nullptr;
+                    q.edge_out = pass + 1 < pl.npass ? T.d_edge[pass & 1] : nullptr;
+                    for (const std::pair<uint32_t, uint32_t> &sg : segs) {
+                        const uint32_t b = std::max(sg.first, part_begin), en = std::min(sg.second, part_end);
+                        if (b >= en) continue;
+                        if (!first_launch)
+                            HIP_TRY(ctx, hipMemsetAsync(q.queue, 0, (size_t)SWG_DYN_SHARDS * SWG_DYN_SHARD_STRIDE * 4, qs));
+                        first_launch = false;
+                        q.q_begin = b;
+                        q.q_end = en;
+                        if (segs.size() > 1) {
+                            q.seg_origin = T.pair_blocks_prefix[sg.first];
+                            q.seg_blocks = T.pair_blocks_prefix[sg.second] - q.seg_origin;
+                        }
+                        HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pform, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
+                        ++launches;
+                        if (split && part == 1) ++f16_launches;
                     }
-                    HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, form, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
                 }
             }
-            if (c == 0) ctx->cur->fill_launches = pl.npass * (int)segs.size();
+            if (c == 0) ctx->cur->fill_launches = launches, ctx->cur->fill_f16_launches = f16_launches;
             continue;
         }
         SwgDiagParams d;
@@ -1239,6 +1263,7 @@ static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess,
     if (n_pairs_guess > 4u * (uint32_t)ctx->n_cu) {
         *out = main_plan;
         out->f16 = 0;
+        out->f16_from = 0;
         return true;
     }
     const int G = 64;
@@ -1661,14 +1686,50 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         q32_ok = db->ptok.ok && q32_list_plan(ctx, lq, 1, &probe) &&
                  (probe.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28)); // (32-bit edge indices)
     }
+    // A query long enough to score beyond 32767 gets the wide form -- but only a sequence that is long itself can get
+    // anywhere near: an exact copy of a stretch of the query scores qbound / lq per row on average, so one of fewer
+    // than 4096 * lq / qbound rows stays below the f16 cells' ceiling even then.  Those (most of a protein database:
+    // 730 rows with BLOSUM62) take the f16 cells, 8.5 instructions per column pair instead of 10, in launches of
+    // their own after the long ones' (launch_diag).  The threshold is an expectation, not a bound: whatever the f16
+    // cells flag all the same is run again on the wide form like any other flagged pair, so results do not depend on it.
+    uint32_t split_at = 0, split_rows = 0;
+    uint64_t split_residues = 0;
+    if (!use_f16 && wide && use_diag && ctx->opt_f16 == 1 && db->f16_veto_epoch != ctx->epoch && -go <= 2048 && -ge <= 2048 &&
+        wk.n_classes == 1 && diag_class_is_dynamic(ctx, db, wk.plan[0]) && !db->tokens_only && qbound > 0) {
+        swg_db *mdb = const_cast<swg_db *>(db);
+        const uint32_t rows = (uint32_t)std::min<uint64_t>((4096ull * lq + qbound - 1) / qbound, 1u << 30);
+        if (mdb->split_rows != rows) { // (per database and threshold: a binary search and one pass over the lengths)
+            const size_t n = db->lens.size();
+            const size_t first_short = (size_t)(std::partition_point(db->lens.begin(), db->lens.end(), [rows](uint32_t l) { return l >= rows; }) -
+                                                db->lens.begin());
+            mdb->split_rows = rows;
+            mdb->split_pair = (uint32_t)((first_short + 1) / 2); // (a pair with one long member is a long pair)
+            uint64_t sum = 0;
+            for (size_t i = std::min(n, (size_t)mdb->split_pair * 2); i < n; ++i) sum += db->lens[i];
+            mdb->split_residues = sum;
+        }
+        const uint32_t cut = std::max<uint32_t>(db->split_pair, (uint32_t)wk.pair_begin[0]);
+        if (cut <= wk.pair_begin[0] && (score_bound < 65535ull || q32_ok)) {
+            // nothing long in this database: the f16 cells for all of it (what they flag: the wide form, as below)
+            use_f16 = true;
+            wide = false;
+            wk.plan[0].wide = 0;
+        } else if (cut > wk.pair_begin[0] && cut < wk.pair_end[0]) {
+            split_at = cut;
+            split_rows = rows;
+            split_residues = db->split_residues;
+        }
+    }
+    wk.plan[0].f16_from = split_at;
     // what the f16 cells flag is run again on int16 cells (the wide form if scores may pass 32767); only what
     // saturates those too needs the int32 kernel
-    const bool rerun_wide = use_f16 && score_bound >= 32767ull && ctx->opt_wide != 0;
+    const bool rerun_wide = (use_f16 && score_bound >= 32767ull && ctx->opt_wide != 0) || split_at != 0u;
     if (use_f16 && score_bound >= (rerun_wide ? 65535ull : 32767ull) && !q32_ok) use_f16 = false;
     for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].f16 = use_f16 ? 1 : 0;
+    const bool some_f16 = use_f16 || split_at != 0u; // some pairs run on the f16 cells: their flags are collected and re-run
     const int32_t ceiling = use_f16 ? 4096 : wide ? 65535 : 32767;
     const SwgDiagPlan &dpl = wk.plan[0];
-    const bool may_saturate = bits == 16 && score_bound >= (uint64_t)ceiling;
+    const bool may_saturate = bits == 16 && (score_bound >= (uint64_t)ceiling || split_at != 0u);
     if (may_saturate) {
         const long keep_cols = ctx->opt_cols;
         ctx->opt_cols = 0; // the int32 re-score uses its default geometry
@@ -1726,7 +1787,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             }
         }
     }
-    const bool int32_level_planned = may_saturate && (!use_f16 || score_bound >= (rerun_wide ? 65535ull : 32767ull));
+    // (the int32 level follows the last 16-bit one: the fill's own cells, or the re-run's when f16 cells came first)
+    const bool int32_level_planned = bits == 16 && score_bound >= (use_f16 ? (rerun_wide ? 65535ull : 32767ull) : (uint64_t)ceiling);
     const bool bin32 = use_diag32 && ((bits == 32 && !use_q32) || (int32_level_planned && !q32_ok)); // the bin-based int32 kernel is needed
     if (bin32) {
         rc = ensure_profile_cols(ctx, 1, (uint32_t)(npass32 * 64 * SWG_DIAG32_K), 4, (1ull << 30) ^ (uint64_t)npass32);
@@ -1811,9 +1873,9 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     int32_t level_ceiling = ceiling; // what the fill before the int32 level saturates at
     bool int32_level = may_saturate;
     uint32_t *seq_list = db->d_list;
-    if (may_saturate && use_f16) {
+    if (may_saturate && some_f16) {
         // counters [17] = flagged pairs (the list's length), [16] = flagged sequences, [6] = their rows / 16 (the veto's input)
-        HIP_TRY(ctx, swg_launch_collect_flagged_pairs(db->d_scores, (uint32_t)(n_slots / 2), ceiling, db->d_list, db->d_counters + 17,
+        HIP_TRY(ctx, swg_launch_collect_flagged_pairs(db->d_scores, split_at, (uint32_t)(n_slots / 2), 4096, db->d_list, db->d_counters + 17,
                                                       db->d_counters + 16, db->d_lens, db->d_counters + 6, s));
         SwgDiagPlan lp;
         const uint32_t guess = db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
@@ -1827,7 +1889,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     if (int32_level) {
         // counters [1] = saturated sequences (the list's length), [6] = their rows in units of 16
         HIP_TRY(ctx, swg_launch_collect_saturated(db->d_scores, (uint32_t)n_slots, level_ceiling, seq_list, db->d_counters + 1,
-                                                  use_f16 ? nullptr : db->d_lens, db->d_counters + 6, s));
+                                                  some_f16 ? nullptr : db->d_lens, db->d_counters + 6, s));
         p.profile = ctx->d_profile[1];
         p.queue = db->d_counters + 2;
         p.list = seq_list;
@@ -1841,7 +1903,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         // search (it did until round 3: a round trip per search, and the end of the two-deep pipeline of
         // swg_search_begin).  Only its lane-group width is a guess -- few flagged sequences get 64 lanes each,
         // many the narrowest group that covers the query -- made from what the last search of this database saw.
-        const uint32_t guess = !use_f16 && db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
+        const uint32_t guess = !some_f16 && db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
         if (use_diag32 && q32_ok && q32_list_plan(ctx, lq, guess, &wkl)) {
             // (fresh queue counters and rank table: the fill's are spent; no events of its own: the
             // re-score is timed as ev[2] .. ev[3] like the other re-score forms)
@@ -1897,7 +1959,9 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     S->use_diag = use_diag;
     S->use_diag32 = use_diag32;
     S->use_q32 = use_q32;
-    S->used_f16 = use_f16;
+    S->used_f16 = some_f16;
+    S->split_rows = split_rows;
+    S->split_residues = split_residues;
     S->epoch = ctx->epoch;
     S->wk32 = wk32;
     S->npass32 = npass32;
@@ -1970,6 +2034,15 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     st.n_rescored = S->used_f16 ? h_counters[16] : h_counters[1];
     st.path_bits = bits;
     st.cell_form = use_diag ? diag_class_form(ctx, db, dpl) : 0;
+    if (use_diag && dpl.f16_from != 0u) {
+        st.cell_form = 4;
+        st.n_rescored = (uint64_t)h_counters[16] + h_counters[1]; // flagged by the f16 cells + saturated on the wide form
+        st.split_rows = (int32_t)S->split_rows;
+        st.fill_f16_launches = S->fill_f16_launches;
+        st.cells_f16 = st.cells / std::max<uint64_t>(1, db->residues) * S->split_residues; // (cells = lq * residues)
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->cur->ev[5], ctx->cur->ev[2]));
+        st.fill_f16_ms = ms;
+    }
     if (may_saturate) {
         // what the next search's plan may assume (never its results)
         swg_db *mdb = const_cast<swg_db *>(db);

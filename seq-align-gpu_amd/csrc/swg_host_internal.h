@@ -77,6 +77,9 @@ struct SwgDiagPlan {
     int variant = 0, K = 0, G = 0, npass = 0, W = 0, workgroups = 0;
     int wide = 0; // scores to 65535 (values biased by -32768)
     int f16 = 0;  // packed-f16 cells with three-operand maxima: scores below 4096, anything above flagged and re-scored
+    // wide && f16_from > 0: both forms in one class -- the pairs before f16_from (the longest: sorted order) on the wide
+    // form, those from it on on the f16 cells (same geometry, a launch each per pass)
+    uint32_t f16_from = 0;
     uint32_t n_streams = 0;
     size_t lds_bytes = 0;
     double est_ms = 0.0;
@@ -127,6 +130,10 @@ struct swg_db {
     // database full of close relatives of the query) that the int16 cells are the faster first step.
     long long sat_hint = -1;
     uint64_t f16_veto_epoch = 0;
+    // both 16-bit forms in one search (swg_search_begin): for the last length threshold asked about, the first pair
+    // of the sorted order whose sequences are all shorter, and the residues from it on
+    uint32_t split_rows = 0, split_pair = 0;
+    uint64_t split_residues = 0;
     // a database whose pair tokens were built straight from reference-shaped 16-lane batches
     // (swg_fill_batches16): there are no residue bytes by sorted rank, so nothing that needs them can run
     bool tokens_only = false;
@@ -172,11 +179,14 @@ struct SwgSlot {
     size_t k = 0, first_chunk = 0;
     bool want_scores = false, dev_topk = false, need_scores = false, two_ends = false, may_saturate = false;
     bool use_diag = false, use_diag32 = false, use_q32 = false;
-    bool used_f16 = false;  // the fill ran on the packed-f16 cells
+    bool used_f16 = false;  // the fill ran on the packed-f16 cells (all of it, or the pairs from plan.f16_from on)
+    uint32_t split_rows = 0;     // both forms: the length threshold, and the residues that ran on the f16 cells
+    uint64_t split_residues = 0;
     uint64_t epoch = 0;     // the context's (query, scoring) epoch the search was queued under
     SwgDiagWork wk32; // int32 work-queue fill of the whole database
     int bits = 0, npass32 = 0, main_K = 0, main_W = 0, main_npass = 0, main_wgs = 0;
     int fill_launches = 0; // launches of the bulk class's fill kernel (passes x segments)
+    int fill_f16_launches = 0; // both forms in one class: those of them that ran the f16 cells
     SwgDiagWork wk;
     swg_stats st;
     uint64_t *h_cand = nullptr;     // pinned, SWG_TOPK_CAND_CAP keys

@@ -239,9 +239,10 @@ hipError_t swg_launch_build_bins(const uint32_t *d_codes, const uint64_t *d_code
 // Appends every slot id whose 16-bit score saturated (>= ceiling: 32767, 65535 in the wide form, 4096 for the
 // packed-f16 cells) to list.
 hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t stream);
-hipError_t swg_launch_collect_flagged_pairs(const int32_t *d_scores, uint32_t n_pairs, int32_t ceiling, uint32_t *d_list,
-                                            uint32_t *d_count, uint32_t *d_seqs, const uint32_t *d_lens, uint32_t *d_rows16,
-                                            hipStream_t stream);
+// (pairs first_pair .. n_pairs-1 of the sorted order: the ones that ran on the f16 cells)
+hipError_t swg_launch_collect_flagged_pairs(const int32_t *d_scores, uint32_t first_pair, uint32_t n_pairs, int32_t ceiling,
+                                            uint32_t *d_list, uint32_t *d_count, uint32_t *d_seqs, const uint32_t *d_lens,
+                                            uint32_t *d_rows16, hipStream_t stream);
 // d_lens / d_rows16 (or NULL): also adds up the flagged sequences' lengths, in units of 16 rows.
 hipError_t swg_launch_collect_saturated(const int32_t *d_scores, uint32_t n_slots, int32_t ceiling,
                                         uint32_t *d_list, uint32_t *d_count, const uint32_t *d_lens, uint32_t *d_rows16,

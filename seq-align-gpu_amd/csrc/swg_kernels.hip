@@ -2752,10 +2752,10 @@ hipError_t swg_launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hi
 // The same by pairs (ranks 2p, 2p+1 share a lane group of the 16-bit fill): pair p is listed once if either of its
 // sequences reached the ceiling; *seqs counts the flagged sequences, *rows16 the rows of the listed pairs in
 // units of 16.
-__global__ void swg_collect_flagged_pairs_kernel(const int32_t *scores, uint32_t n_pairs, int32_t ceiling, uint32_t *list,
-                                                 uint32_t *count, uint32_t *seqs, const uint32_t *lens, uint32_t *rows16)
+__global__ void swg_collect_flagged_pairs_kernel(const int32_t *scores, uint32_t first_pair, uint32_t n_pairs, int32_t ceiling,
+                                                 uint32_t *list, uint32_t *count, uint32_t *seqs, const uint32_t *lens, uint32_t *rows16)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = first_pair + blockIdx.x * blockDim.x + threadIdx.x; // (pairs before first_pair ran on other cells)
     if (p >= n_pairs) return;
     const uint32_t fx = scores[2u * p] >= ceiling, fy = scores[2u * p + 1u] >= ceiling;
     if (fx | fy) {
@@ -2765,13 +2765,13 @@ __global__ void swg_collect_flagged_pairs_kernel(const int32_t *scores, uint32_t
     }
 }
 
-hipError_t swg_launch_collect_flagged_pairs(const int32_t *d_scores, uint32_t n_pairs, int32_t ceiling, uint32_t *d_list,
-                                            uint32_t *d_count, uint32_t *d_seqs, const uint32_t *d_lens, uint32_t *d_rows16,
-                                            hipStream_t stream)
+hipError_t swg_launch_collect_flagged_pairs(const int32_t *d_scores, uint32_t first_pair, uint32_t n_pairs, int32_t ceiling,
+                                            uint32_t *d_list, uint32_t *d_count, uint32_t *d_seqs, const uint32_t *d_lens,
+                                            uint32_t *d_rows16, hipStream_t stream)
 {
-    if (n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(swg_collect_flagged_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, d_scores, n_pairs,
-                       ceiling, d_list, d_count, d_seqs, d_lens, d_rows16);
+    if (n_pairs <= first_pair) return hipSuccess;
+    hipLaunchKernelGGL(swg_collect_flagged_pairs_kernel, dim3((n_pairs - first_pair + 255) / 256), dim3(256), 0, stream, d_scores,
+                       first_pair, n_pairs, ceiling, d_list, d_count, d_seqs, d_lens, d_rows16);
     return hipGetLastError();
 }
 

@@ -387,11 +387,29 @@ def test_wide16_range_and_beyond(swg, ctx, orc, geom, f16):
     db = swg.Database(flat, off).upload(ctx)
     got, hits, st = ctx.search(db, k=10)
     assert np.array_equal(got, want), (geom, st)
-    assert st["cell_form"] == (2 if f16 == 2 else 1)
-    assert st["n_rescored"] == int((want >= (4096 if f16 == 2 else 65535)).sum()) and st["engine"] == 2
+    assert st["cell_form"] == 2 if f16 == 2 else st["cell_form"] in (1, 4)
+    if st["cell_form"] == 4:    # (one class, default f16: the sequences under split_rows rows on the f16 cells)
+        lens_a = np.asarray(lens)
+        assert 0 < st["split_rows"] < 400 and st["cells_f16"] == len(q) * int(lens_a[_f16_part(lens_a, st["split_rows"])].sum())
+        assert st["n_rescored"] == int((want >= 65535).sum()) + int((want[_f16_part(lens_a, st["split_rows"])] >= 4096).sum())
+    else:
+        assert st["n_rescored"] == int((want >= (4096 if f16 == 2 else 65535)).sum())
+    assert st["engine"] == 2
     assert hits == orc.topk(want, 10)
     db.close()
     _reset_options(ctx)
+
+
+def _f16_part(lens, split_rows):
+    """Which sequences of a database the both-forms search (cell_form 4) ran on the f16 cells: by sorted rank (length
+    descending, stable) the pairs (2i, 2i+1) whose longer member is under split_rows rows."""
+    lens = np.asarray(lens)
+    order = np.argsort(-lens.astype(np.int64), kind="stable")
+    n_long = int((lens >= split_rows).sum())
+    first = (n_long + 1) // 2 * 2
+    part = np.zeros(len(lens), dtype=bool)
+    part[order[first:]] = True
+    return part
 
 
 @pytest.mark.parametrize("lq,opts", [(1300, {}), (1300, {"segment_blocks": 700}), (2600, {"cols_per_wave": 16, "group_lanes": 16}),
@@ -913,6 +931,65 @@ def test_config5_every_sequence_similar(swg, ctx, orc):
     db.close()
 
 
+@pytest.mark.parametrize("opts", [{}, {"segment_blocks": 3000}, {"cols_per_wave": 24, "group_lanes": 32, "max_waves": 4, "long_split": -1}])
+@pytest.mark.parametrize("long_ones", [True, False])
+def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones):
+    """A query that can score beyond 32767 (wide form) against a database of mostly short sequences: those under
+    4096 * lq / qbound rows run on the f16 cells, the longer ones on the wide form, in launches of their own per pass
+    (swg_stats.cell_form 4).  The threshold is an expectation, so the database also holds what defeats it: runs of
+    400-500 tryptophans (11 per match, 4400-5500 for fewer rows than the threshold), which the f16 cells must flag and the
+    wide form score again; near-copies of the whole query (beyond 32767, on the wide form from the start).  Without any
+    long sequence (long_ones False) the whole search runs on the f16 cells and what they flag on the wide form.  All
+    scores against the oracle, twice (the second search plans the re-run from what the first one saw), also with the
+    passes cut into segments and with a forced geometry."""
+    sc = swg.load_scoring("BLOSUM62")
+    # (an entry no sequence here uses, so that "longest sequence x largest entry" does not cap the score bound below
+    # 32767 when every sequence is short: the search without long ones must still plan for the wide range)
+    sc.sub[21][21] = 127
+    rng = np.random.default_rng(404)
+    w = swg.synth_query(1, 1)
+    w[:] = 23  # 'W'
+    q = np.concatenate([swg.synth_query(91, 1250), np.repeat(w, 2000), swg.synth_query(92, 1250)])
+    assert not (q == 21).any()
+    lens = [int(v) for v in rng.integers(20, 500, size=900)]
+    seqs = [swg.synth_query(3000 + i, L) for i, L in enumerate(lens)]
+    for i, L in enumerate((400, 430, 470, 500, 380)):                   # tryptophan runs: short, but beyond the f16 ceiling
+        seqs[50 + 7 * i] = np.repeat(w, L)
+        lens[50 + 7 * i] = L
+    if long_ones:
+        for L in (4500, 4400, 3000, 2200, 1500, 900, 700, 650):         # (prefixes of the query: the W run is inside from 1250 on)
+            seqs.append(q[:L].copy())
+            lens.append(L)
+        for i, L in enumerate(int(v) for v in rng.integers(560, 1400, size=40)):
+            seqs.append(swg.synth_query(5000 + i, L))
+            lens.append(L)
+    flat = np.concatenate(seqs)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    assert ((want >= 4096) & (np.asarray(lens) <= 500)).sum() >= 4 and (not long_ones or (want > 32767).sum() >= 2)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    ctx.set_option("autotune", 0)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    db = swg.Database(flat, off).upload(ctx)
+    for attempt in range(2):
+        got, hits, st = ctx.search(db, k=20)
+        assert np.array_equal(got, want), (attempt, opts, st, np.nonzero(got != want)[0][:8])
+        assert hits == orc.topk(want, 20) and st["passes"] > 1
+        if long_ones:
+            part = _f16_part(np.asarray(lens), st["split_rows"])
+            assert st["cell_form"] == 4 and 500 < st["split_rows"] < 560 and st["cells_f16"] == len(q) * int(np.asarray(lens)[part].sum()), st
+            assert st["n_rescored"] == int((want[part] >= 4096).sum()) + int((want >= 65535).sum())
+        else:
+            assert st["cell_form"] == 2 and st["n_rescored"] == int((want >= 4096).sum()), st
+    db.close()
+    _reset_options(ctx)
+    ctx.set_option("autotune", 1)
+
+
 def test_config5_one_gpu_share_with_flagged_rescore(swg, ctx, orc):
     """Config 5 as BASELINE names it ("forcing 16->32-bit rescore") at one GPU's share of SURVEY 8d's shape: 1.25
     million sequences, 1 % of them near-copies of the 8192-aa query (what bench.py's config-5 block and its `rescore`
@@ -932,9 +1009,18 @@ def test_config5_one_gpu_share_with_flagged_rescore(swg, ctx, orc):
     ctx.set_option("autotune", 0)
     db = swg.Database(flat, off).upload(ctx)
     wide, hits, st = ctx.search(db, k=100)
-    assert st["path_bits"] == 16 and st["cell_form"] == 1 and st["n_rescored"] == 0 and st["passes"] > 1
+    # (default: both forms -- the near-copies and everything else of 4096 * lq / qbound rows or more on the wide form,
+    # the rest on the f16 cells, which flag nothing here)
+    assert st["path_bits"] == 16 and st["cell_form"] == 4 and st["n_rescored"] == 0 and st["passes"] > 1
+    lens_all = np.diff(off.astype(np.int64))
+    assert 600 < st["split_rows"] < 900 and st["cells_f16"] == lq * int(lens_all[_f16_part(lens_all, st["split_rows"])].sum())
+    assert 0.5 * st["cells"] < st["cells_f16"] < 0.8 * st["cells"] and 0 < st["fill_f16_ms"] < st["fill_ms"]
+    ctx.set_option("f16", 0)
+    only_wide, hits_w, st_w = ctx.search(db, k=100)
+    assert st_w["cell_form"] == 1 and st_w["n_rescored"] == 0 and np.array_equal(only_wide, wide) and hits_w == hits
     ctx.set_option("wide16", 0)
     plain, hits16, st16 = ctx.search(db, k=100)
+    ctx.set_option("f16", 1)
     ctx.set_option("wide16", 1)
     ctx.set_option("autotune", 1)
     db.close()

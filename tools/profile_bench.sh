@@ -2,7 +2,7 @@
 # counters in their own passes (MI355X_MICROARCH.md, HBM / rocprofv3 PMC sections), then SQ / LDS counters.
 #   bash tools/profile_bench.sh <config> [steps] [traffic key]  -> gpurun_out/prof_c<config>/{summary,traffic}.json
 # The traffic key is what bench.py looks up in profiles/traffic.json: config<C>_f16 for the packed-f16 cells (the default
-# for configs 2-4), config<C>_wide for the wide int16 form (config 5), config<C> for the int16 cells, config<C>_int32.  FETCH_SIZE is doubled: on gfx950 it reports half the
+# for configs 2-4), config<C>_wide for the wide int16 form, config<C>_split for both forms in one search (config 5: the f16 launches' traffic), config<C> for the int16 cells, config<C>_int32.  FETCH_SIZE is doubled: on gfx950 it reports half the
 # bytes fetched, for every load shape of these kernels (tools/fetch_probe.hip, profiles/r03_fetch_size_probe.txt).
 CFG=${1:-3}
 STEPS=${2:-${STEPS:-20}}
@@ -34,6 +34,8 @@ json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 # bytes, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes, mean per launch
 # (the main fill only: "diag_dyn" / "fill_kernel"; a configuration's re-score leg runs swg_diag32q_kernel, listed in the summary)
 fill = {k: cs for k, cs in summary["pmc_mean_per_launch"].items() if ("diag_dyn" in k or "diag_kernel" in k or "fill_kernel" in k) and "FETCH_SIZE" in cs}
+if "$KEY".endswith("_split"):   # both 16-bit forms in one search: the dominant kernel's launches only (the f16 cells, FORM 2)
+    fill = {k: cs for k, cs in fill.items() if k.rstrip().endswith(", 2>")}
 fetch = sum(cs["FETCH_SIZE"] for cs in fill.values()); write = sum(cs.get("WRITE_SIZE", 0.0) for cs in fill.values())
 json.dump({"$KEY": {"hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh), mean per launch, summed over the fill kernels of one search; KiB -> bytes; FETCH_SIZE doubled (gfx950 correction of the guide's HBM section; factor 2.000 measured for these kernels' load shapes: profiles/r03_fetch_size_probe.txt)",
