@@ -20,7 +20,7 @@ def _check_block(b, n_gpus=1):
     # value = cells of the WHOLE database * steps / elapsed: consistent with ms_per_step and the workload
     cells = b["config"]["lq"] * b["config"]["residues_total"]
     assert abs(b["value"] - cells / (b["ms_per_step"] * 1e-3) / 1e9) < 0.01 * b["value"]
-    assert b["unit"] == "GCUPS" and b["dtype"] in ("int16", "int32", "f16")
+    assert b["unit"] == "GCUPS" and b["dtype"] in ("int16", "int32", "f16", "f16+int16")
     assert r["kernel_ms"] * r.get("launches_per_step", 1) <= b["ms_per_step"] * 1.02
     assert b.get("verify", {"ok": True})["ok"] is True
 
