@@ -14,6 +14,7 @@ def main(budget=300.0, seed=1):
     mats = ["BLOSUM62", "PAM250", "BLOSUM45"]
     t_end = time.time() + budget
     cases = 0
+    forms = {}   # searches by swg_stats.cell_form
     ks = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 16, 17, 20, 23, 24, 25, 28, 31, 32]
     while time.time() < t_end:
         shape = rng.integers(0, 5)
@@ -39,7 +40,14 @@ def main(budget=300.0, seed=1):
             q[rng.random(lq) < 0.9] = 23
             sc = swg.load_scoring("PAM250")
             lens = [int(v) for v in rng.integers(1500, lq + 1, size=4)] + [int(v) for v in rng.integers(1, 200, size=int(rng.integers(1, 300)))]
+            # (both 16-bit forms in one search: decoys either side of its length cut, and tryptophan runs that beat the
+            # f16 ceiling from below the cut)
+            lens += [int(v) for v in rng.integers(200, 700, size=int(rng.integers(0, 40)))]
+            n_runs = int(rng.integers(0, 6))
+            lens += [int(v) for v in rng.integers(200, 420, size=n_runs)]
             seqs = [q[:L].copy() if i < 4 else swg.synth_query(int(rng.integers(1, 1 << 30)), L) for i, L in enumerate(lens)]
+            for s_ in seqs[len(seqs) - n_runs:]:
+                s_[:] = 23
         if rng.random() < 0.3 and lq > 50:   # plant similar sequences
             for i in rng.integers(0, len(seqs), size=min(5, len(seqs))):
                 L = len(seqs[i]); m = min(L, lq); seqs[i][:m] = q[:m]
@@ -89,9 +97,10 @@ def main(budget=300.0, seed=1):
             return 1
         db.close()
         cases += 1
+        forms[int(st["cell_form"])] = forms.get(int(st["cell_form"]), 0) + 1
         if cases % 25 == 0:
             print("cases", cases, "last: n", n, "lq", lq, "opts", opts, "engine", st["engine"], "K", st["cols_per_wave"], "G", st["group_lanes"], "P", st["passes"], "wq", st["work_queue"], flush=True)
-    print("OK", cases, "cases")
+    print("OK", cases, "cases; by cell form", dict(sorted(forms.items())))
     return 0
 
 if __name__ == "__main__":
