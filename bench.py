@@ -63,11 +63,13 @@ CONFIGS = {
     4: dict(lq=3000, n=1250000, matrix="BLOSUM62", n_full=10000000),   # n: one GPU's eighth of the 10M-sequence DB
     # one GPU's eighth of SURVEY 8d's 10M sequences, 1 % of them near-copies of the query
     5: dict(lq=8192, n=1250000, matrix="BLOSUM62", similar=0.01, n_full=10000000),
+    # SURVEY 8d's stress variant of config 5: 100 000 sequences, every one a near-copy of the query (block "5_stress")
+    6: dict(lq=8192, n=100000, matrix="BLOSUM62", similar=1.0),
 }
 # BASELINE.json names config 5 "forcing 16->32-bit rescore": its block carries, beside the library's own choice
 # (the wide int16 form, exact to 65535: nothing left to re-score), the same database with plain int16 cells,
 # every flagged sequence re-scored by the int32 work-queue kernel.
-CONFIG_LEGS = {5: (("rescore", {"wide16": 0}),)}
+CONFIG_LEGS = {5: (("rescore", {"wide16": 0}),), 6: (("rescore", {"wide16": 0}),)}
 HEADLINE = 3            # largest single-GPU configuration of BASELINE.json
 SHARDED = 4             # the configuration N > 1 runs, as one database dealt by bins
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak
@@ -332,8 +334,8 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
             workload = ("config %d: 1 query (%d aa) vs ONE %d-seq synthetic protein DB dealt by bins over %d GPU(s), "
                         "%s, gaps %d/%d, global top-%d by one RCCL all-reduce" % (cnum, lq, n, env.world, cfg["matrix"], a.gapopen, a.gapextend, K))
         else:
-            workload = ("config %d: 1 query (%d aa) vs %d-seq synthetic protein DB%s, %s, gaps %d/%d, top-%d"
-                        % (cnum, lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], a.gapopen, a.gapextend, K))
+            workload = ("config %s: 1 query (%d aa) vs %d-seq synthetic protein DB%s, %s, gaps %d/%d, top-%d"
+                        % ("5 (stress variant)" if cnum == 6 else str(cnum), lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], a.gapopen, a.gapextend, K))
             if cnum == 4 and not n_override:
                 workload += " (one GPU's eighth of the 10M-sequence database)"
             if cfg.get("similar"):
@@ -802,6 +804,7 @@ def main():
             blocks["2"] = run_config(env, 2, K, W, host_inclusive_leg=True)
             blocks["4"] = run_config(env, 4, max(2, K // 5), min(W, 2))
             blocks["5"] = run_config(env, 5, 2, 1, legs=CONFIG_LEGS[5])
+            blocks["5_stress"] = run_config(env, 6, 2, 1, legs=CONFIG_LEGS[6])
             if "host_inclusive" in blocks["2"]:
                 out["host_inclusive"] = blocks["2"]["host_inclusive"]      # quoted on config 2, as in round 1
             if not args.no_scaling_reference:
