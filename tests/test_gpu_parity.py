@@ -988,6 +988,40 @@ def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones):
     ctx.set_option("autotune", 1)
 
 
+@pytest.mark.parametrize("wide16", [1, 0])
+def test_titin_sized_query(swg, ctx, orc, wide16):
+    """The longest proteins known are about 35 000 residues: a 36 000-aa query (18 passes of 2048 columns) against
+    prefixes of itself -- scores far beyond 65535, so the 16-bit forms flag them and the int32 work-queue kernel scores
+    them over its own passes --, sequences either side of the both-forms cut, and one sequence longer than the query.
+    wide16 = 0: plain int16 cells first, everything from 32767 up re-scored."""
+    sc = swg.load_scoring("BLOSUM62")
+    lq = 36000
+    q = swg.synth_query(0x717, lq)
+    rng = np.random.default_rng(717)
+    lens = [36000, 30011, 14000, 9000, 6500, 2000] + [int(v) for v in rng.integers(1, 1500, size=150)] + [40000]
+    seqs = [q[:L].copy() if i < 6 else swg.synth_query(7000 + i, L) for i, L in enumerate(lens)]
+    seqs[3][::7] = 1                                  # (a relative with substitutions, not a copy)
+    flat = np.concatenate(seqs)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    assert (want >= 65535).sum() >= 2 and ((want >= 32767) & (want < 65535)).sum() >= 1 and (want < 4096).sum() > 100
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    ctx.set_option("autotune", 0)
+    ctx.set_option("wide16", wide16)
+    db = swg.Database(flat, off).upload(ctx)
+    for attempt in range(2):
+        got, hits, st = ctx.search(db, k=8)
+        assert np.array_equal(got, want), (attempt, st, np.nonzero(got != want)[0][:8])
+        assert hits == orc.topk(want, 8) and st["passes"] >= 18 and st["path_bits"] == 16
+        assert st["cell_form"] == (4 if wide16 else 0), st
+    db.close()
+    _reset_options(ctx)
+    ctx.set_option("autotune", 1)
+
+
 def test_config5_one_gpu_share_with_flagged_rescore(swg, ctx, orc):
     """Config 5 as BASELINE names it ("forcing 16->32-bit rescore") at one GPU's share of SURVEY 8d's shape: 1.25
     million sequences, 1 % of them near-copies of the 8192-aa query (what bench.py's config-5 block and its `rescore`
