@@ -118,6 +118,7 @@ def parse_args():
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--last-pass", type=int, default=-1, help="experiment: 0 = the last pass of a long query with the other passes' geometry")
     ap.add_argument("--f16", type=int, default=-1, help="experiment: 0 = int16 cells only, 2 = f16 cells whenever the gap scores allow")
     ap.add_argument("--wide16", type=int, default=-1, help="experiment: 0 = plain int16 cells + int32 re-score instead of the wide form")
     ap.add_argument("--gapopen", type=int, default=-2, help="experiment: gap_open (the configurations use the reference's default -2)")
@@ -200,6 +201,8 @@ def make_context(env, q, sc):
         ctx.set_option("prio_share", a.prio_share)
     if a.f16 >= 0:
         ctx.set_option("f16", a.f16)
+    if a.last_pass >= 0:
+        ctx.set_option("last_pass", a.last_pass)
     if a.wide16 >= 0:
         ctx.set_option("wide16", a.wide16)
     return ctx
@@ -390,6 +393,7 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
 def plan_of(last):
     """What the library chose for a search, from its stats record."""
     return {"cols_per_wave": last["cols_per_wave"], "waves": last["waves"], "passes": last["passes"],
+            "last_pass_cols": last["last_pass_cols"],
             "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
             "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
             "cells": {0: "packed int16", 1: "packed int16, wide form (to 65535)",
@@ -469,6 +473,11 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     else:
         ops_per_cell = 5.0 if last["path_bits"] == 16 else 12.0
         kname = "swg_fill_kernel<CellsI%d>" % last["path_bits"]
+    if q16 and form != 4 and int(last["last_pass_cols"]) > 0 and int(last["passes"]) > 1:
+        # the last pass of a long query runs an instantiation with fewer columns per lane: kernel_ms is the mean over
+        # all the launches of one search's fill, i.e. rocprofv3's two per-kernel averages weighted by their calls
+        per_pass = launches // int(last["passes"])
+        kname += " x%d + <K=%d> x%d (the last pass) per search" % (launches - per_pass, last["last_pass_cols"], per_pass)
     simds = 256 * 4
     kernel_gcups = cells_local / (step_fill_ms * 1e-3) / 1e9
     peak_issue = simds * 64 / 4.0 * 2.4e9 / ops_per_cell / 1e9

@@ -105,6 +105,8 @@ typedef struct swg_stats {
     int32_t fill_f16_launches; /* cell_form 4: how many of fill_launches ran the f16 cells; else 0 */
     double fill_f16_ms;     /* cell_form 4: the part of fill_ms spent on the f16 cells; else 0 */
     uint64_t cells_f16;     /* cell_form 4: the real cells computed on the f16 cells; else 0 */
+    int32_t last_pass_cols; /* diagonal engine, several passes: columns per lane of the last pass when it has a geometry of
+                             * its own (fewer than cols_per_wave); else 0 */
 } swg_stats;
 
 /* ---- context ---------------------------------------------------------- */
@@ -137,8 +139,11 @@ int swg_abi_version(void);
  * re-scored in int32 | 0: plain int16 and int32 re-score from 32767), "f16" (1 default: the diagonal engine's
  * 16-bit fill runs on packed-f16 cells -- gfx950's three-operand maxima, 8.5 instead of 10 instructions per
  * column pair, exact below 4096, every sequence that reaches 4096 flagged and re-scored in int32 -- unless the
- * query is long enough for scores beyond 32767 or this database has flagged more than 2 % of its rows for this
- * query | 0: int16 cells only | 2: f16 cells whenever the gap magnitudes are at most 2048), "qq" (1 default: a batch of
+ * query is long enough for scores beyond 32767 (then the sequences too short to get there still do and the rest
+ * runs on the wide form: swg_stats.cell_form 4) or this database has flagged more than 2 % of its rows for this
+ * query | 0: int16 cells only | 2: f16 cells whenever the gap magnitudes are at most 2048), "last_pass" (1 default: the
+ * last pass of a query of several passes runs with the fewest columns per lane that cover what is left | 0: like the
+ * other passes), "qq" (1 default: a batch of
  * queries on the f16 cells runs two queries per lane | 0: two sequences per lane as a single query does), "side_readout" (1 default:
  * top-K selection and read-out of a search run on their own stream, beside the fill of the search
  * queued next). */

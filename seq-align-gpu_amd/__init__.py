@@ -81,6 +81,7 @@ class Stats(C.Structure):
         ("fill_f16_launches", C.c_int32),
         ("fill_f16_ms", C.c_double),
         ("cells_f16", C.c_uint64),
+        ("last_pass_cols", C.c_int32),
     ]
 
     def as_dict(self):

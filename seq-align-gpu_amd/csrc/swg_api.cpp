@@ -201,6 +201,8 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
     } else if (!strcmp(key, "f16")) {
         if (value < 0 || value > 2) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "f16 must be 0 (off), 1 (auto) or 2 (whenever the gap scores allow)");
         ctx->opt_f16 = value;
+    } else if (!strcmp(key, "last_pass")) {
+        ctx->opt_last_pass = value != 0;
     } else if (!strcmp(key, "qq")) {
         ctx->opt_qq = value != 0;
     } else if (!strcmp(key, "long_helps")) {
@@ -471,13 +473,16 @@ static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
     return SWG_OK;
 }
 
+// tail_cols > 0: the last tail_cols layout columns (one pass) have a slice geometry of their own, tail_k_real query
+// columns in tail_k_padded layout columns per lane, and begin at query column tail_qcol0.
 static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem_size, uint64_t geom, int k_real = 1,
-                               int k_padded = 1, int chunk_cols = 4, int swizzle_lanes = 0, int f16 = 0)
+                               int k_padded = 1, int chunk_cols = 4, int swizzle_lanes = 0, int f16 = 0, uint32_t tail_cols = 0,
+                               int tail_k_real = 0, int tail_k_padded = 0, uint32_t tail_qcol0 = 0)
 {
     const size_t bytes = (size_t)ncols * 32 * elem_size;
     // (query, scoring) epoch and geometry: the epoch is spread over all 64 bits so that no geometry field can alias it
     const uint64_t tag = (ctx->epoch * 0x9E3779B97F4A7C15ull) ^ geom ^ ((uint64_t)swizzle_lanes << 56) ^ ((uint64_t)chunk_cols << 60) ^
-                         ((uint64_t)(f16 != 0) << 53);
+                         ((uint64_t)(f16 != 0) << 53) ^ (((uint64_t)tail_cols * 0xD6E8FEB86659FD93ull) ^ ((uint64_t)tail_k_real << 24));
     if (ctx->profile_tag[which] == tag && ctx->d_profile[which]) return SWG_OK;
     if (bytes > ctx->d_profile_cap[which]) {
         (void)hipFree(ctx->d_profile[which]);
@@ -486,9 +491,13 @@ static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem
         HIP_TRY(ctx, hipMalloc(&ctx->d_profile[which], bytes));
         ctx->d_profile_cap[which] = bytes;
     }
-    HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols,
+    HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), ncols - tail_cols,
                                           elem_size, chunk_cols, k_real, k_padded, ctx->d_profile[which], ctx->stream,
                                           swizzle_lanes, f16));
+    if (tail_cols > 0)
+        HIP_TRY(ctx, swg_launch_build_profile(ctx->d_sub, ctx->d_query, (uint32_t)ctx->query.size(), tail_cols, elem_size, chunk_cols,
+                                              tail_k_real, tail_k_padded, ctx->d_profile[which] + (size_t)(ncols - tail_cols) * 32 * elem_size,
+                                              ctx->stream, swizzle_lanes, f16, tail_qcol0));
     ctx->profile_tag[which] = tag;
     return SWG_OK;
 }
@@ -718,14 +727,19 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
             db->ptok.edge_blocks = db->ptok.total_blocks;
         }
         const int kp = swg_diag_padded_cols(pl.K);
-        const uint32_t ncols = (uint32_t)(pl.npass * pl.G * kp);
+        // (a last pass with a geometry of its own: its slice follows the other passes' in the same buffer)
+        const bool own_last = pl.npass > 1 && pl.last_variant >= 0 && diag_class_is_dynamic(ctx, db, pl);
+        const int kp_last = own_last ? swg_diag_padded_cols(pl.last_K) : kp;
+        const uint32_t tail = own_last ? (uint32_t)(pl.G * kp_last) : 0u;
+        const uint32_t ncols = (uint32_t)((pl.npass - (own_last ? 1 : 0)) * pl.G * kp) + tail;
+        const uint32_t qcol0 = (uint32_t)((pl.npass - 1) * pl.G * pl.K);
         int rc = ensure_profile_cols(ctx, diag_profile_slot(pl, c), ncols, 2,
                                      (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols, pl.K, kp, 4,
-                                     SWG_LDS_SWIZZLE ? pl.G : 0, diag_class_form(ctx, db, pl) == 2);
+                                     SWG_LDS_SWIZZLE ? pl.G : 0, diag_class_form(ctx, db, pl) == 2, tail, pl.last_K, kp_last, qcol0);
         if (rc != SWG_OK) return rc;
         if (pl.wide && pl.f16_from > 0) { // both forms in this class: the f16 cells' profile of the same geometry
             rc = ensure_profile_cols(ctx, 7, ncols, 2, (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols,
-                                     pl.K, kp, 4, SWG_LDS_SWIZZLE ? pl.G : 0, 1);
+                                     pl.K, kp, 4, SWG_LDS_SWIZZLE ? pl.G : 0, 1, tail, pl.last_K, kp_last, qcol0);
             if (rc != SWG_OK) return rc;
         }
     }
@@ -853,7 +867,8 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                             q.seg_origin = T.pair_blocks_prefix[sg.first];
                             q.seg_blocks = T.pair_blocks_prefix[sg.second] - q.seg_origin;
                         }
-                        HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, edges, pform, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
+                        const int variant = pass + 1 == pl.npass && pl.npass > 1 && pl.last_variant >= 0 ? pl.last_variant : pl.variant;
+                        HIP_TRY(ctx, swg_launch_diag_dyn(variant, edges, pform, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
                         ++launches;
                         if (split && part == 1) ++f16_launches;
                     }
@@ -1264,6 +1279,8 @@ static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess,
         *out = main_plan;
         out->f16 = 0;
         out->f16_from = 0;
+        out->last_variant = -1;
+        out->last_K = 0;
         return true;
     }
     const int G = 64;
@@ -1721,6 +1738,22 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         }
     }
     wk.plan[0].f16_from = split_at;
+    // Several passes of G*K columns each leave the last one partly empty (3000 columns in 6 passes of 512: 72 of them,
+    // 2.3 % of the work): it runs the instantiation with the fewest columns per lane that cover what is left.
+    for (int c = 0; c < wk.n_classes; ++c) {
+        SwgDiagPlan &pl = wk.plan[c];
+        pl.last_variant = -1;
+        pl.last_K = 0;
+        if (!use_diag || wk.n_classes != 1 || pl.npass < 2 || !diag_class_is_dynamic(ctx, db, pl) || ctx->opt_last_pass == 0) continue;
+        const size_t rest = lq - (size_t)(pl.npass - 1) * pl.G * pl.K;
+        const int need = (int)((rest + pl.G - 1) / pl.G);
+        int best = -1, bestK = pl.K;
+        for (int v = 0; v < swg_num_diag_variants(); ++v) {
+            const SwgKernelInfo info = swg_diag_variant_info(v);
+            if (info.K >= need && info.K < bestK && pl.W <= info.max_waves) best = v, bestK = info.K;
+        }
+        if (best >= 0) pl.last_variant = best, pl.last_K = bestK;
+    }
     // what the f16 cells flag is run again on int16 cells (the wide form if scores may pass 32767); only what
     // saturates those too needs the int32 kernel
     const bool rerun_wide = (use_f16 && score_bound >= 32767ull && ctx->opt_wide != 0) || split_at != 0u;
@@ -2070,7 +2103,9 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         st.workgroups = diag_class_workgroups(ctx, db, wk, 0);
         st.work_queue = diag_class_is_dynamic(ctx, db, dpl) ? 1 : 0;
         st.streams = (int32_t)diag_class_streams(ctx, db, wk, 0);
-        st.cells_padded = 2ull * dpl.npass * dpl.G * dpl.K * diag_class_blocks(ctx, db, wk, 0) * 4ull;
+        st.cells_padded = 2ull * ((uint64_t)(dpl.npass - (dpl.last_variant >= 0 ? 1 : 0)) * dpl.K + (dpl.last_variant >= 0 ? dpl.last_K : 0)) *
+                          dpl.G * diag_class_blocks(ctx, db, wk, 0) * 4ull;
+        st.last_pass_cols = dpl.last_variant >= 0 ? dpl.last_K : 0;
         if (wk.n_classes == 2) {
             const SwgDiagPlan &lp = wk.plan[1];
             st.long_pairs = (int32_t)(wk.pair_end[1] - wk.pair_begin[1]);

@@ -80,6 +80,9 @@ struct SwgDiagPlan {
     // wide && f16_from > 0: both forms in one class -- the pairs before f16_from (the longest: sorted order) on the wide
     // form, those from it on on the f16 cells (same geometry, a launch each per pass)
     uint32_t f16_from = 0;
+    // Several passes: the last one covers what is left of the query with the fewest columns per lane that do
+    // (its own kernel instantiation and profile layout; edges do not depend on the geometry).  -1: as the others.
+    int last_variant = -1, last_K = 0;
     uint32_t n_streams = 0;
     size_t lds_bytes = 0;
     double est_ms = 0.0;
@@ -228,7 +231,7 @@ struct swg_ctx {
     hipEvent_t ev_query_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     int query_stage_next = 0;
     // options
-    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 0, opt_wide = 1, opt_side_readout = 1, opt_f16 = 1, opt_qq = 1;
+    long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 0, opt_wide = 1, opt_side_readout = 1, opt_f16 = 1, opt_qq = 1, opt_last_pass = 1;
     uint32_t opt_seg_blocks = SWG_DYN_SEG_BLOCKS; // token blocks per launch of the multi-pass fill (option "segment_blocks": tests)
     // device state
     int8_t *d_sub = nullptr;

@@ -218,7 +218,8 @@ hipError_t swg_launch_build_profiles_multi(const int8_t *d_sub, const int8_t *d_
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query,
                                     uint32_t lq, uint32_t ncols, int elem_size, int chunk_cols, int k_real,
                                     int k_padded, uint8_t *d_profile, hipStream_t stream, int swizzle_lanes = 0,
-                                    int f16 = 0); // f16: elem_size 2 entries are f16 numbers (pad -65504) for the packed-f16 cells
+                                    int f16 = 0, // f16: elem_size 2 entries are f16 numbers (pad -65504) for the packed-f16 cells
+                                    uint32_t qcol0 = 0); // the query column layout column 0 stands for
 int swg_diag_padded_cols(int K); // layout columns of a lane's slice
 
 // Per-database layouts from the uploaded residue dwords (d_code_off in dwords): the pair-major

@@ -1944,13 +1944,14 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
 // ---------------------------------------------------------------------------
 __global__ void swg_build_profile_kernel(const int8_t *sub, const int8_t *query, uint32_t lq,
                                          uint32_t ncols, int elem_size, uint32_t ch, uint32_t k_real,
-                                         uint32_t k_padded, uint32_t swizzle_lanes, int f16, uint8_t *out)
+                                         uint32_t k_padded, uint32_t swizzle_lanes, int f16, uint32_t qcol0, uint8_t *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // one (layout column, code)
     if (t >= ncols * 32u) return;
     const uint32_t col = t >> 5, code = t & 31u;
-    // a lane's slice is k_padded layout columns of which the first k_real are query columns
-    const uint32_t j = col % k_padded, qcol = (col / k_padded) * k_real + j;
+    // a lane's slice is k_padded layout columns of which the first k_real are query columns (qcol0: the query
+    // column of layout column 0 -- the last pass of a long query may have a geometry of its own)
+    const uint32_t j = col % k_padded, qcol = qcol0 + (col / k_padded) * k_real + j;
     const bool pad = (j >= k_real) || (qcol >= lq) || (code == 0u);
     const int v = pad ? 0 : (int)sub[(int)query[qcol] * 32 + (int)code];
     // row of this residue inside its chunk: the residue itself, or swizzled by the reading lane (SWG_LDS_SWIZZLE)
@@ -2720,12 +2721,13 @@ hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups, const S
 
 hipError_t swg_launch_build_profile(const int8_t *d_sub, const int8_t *d_query, uint32_t lq,
                                     uint32_t ncols, int elem_size, int chunk_cols, int k_real, int k_padded,
-                                    uint8_t *d_profile, hipStream_t stream, int swizzle_lanes, int f16)
+                                    uint8_t *d_profile, hipStream_t stream, int swizzle_lanes, int f16, uint32_t qcol0)
 {
     const uint32_t n = ncols * 32u;
+    if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(swg_build_profile_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_sub,
                        d_query, lq, ncols, elem_size, (uint32_t)chunk_cols, (uint32_t)k_real, (uint32_t)k_padded,
-                       (uint32_t)swizzle_lanes, f16, d_profile);
+                       (uint32_t)swizzle_lanes, f16, qcol0, d_profile);
     return hipGetLastError();
 }
 

@@ -56,7 +56,7 @@ def main(budget=300.0, seed=1):
         ctx.set_scoring(sc, go, ge); ctx.set_query(q)
         for k in ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups", "segment_blocks"):
             ctx.set_option(k, 0)
-        for k in ("work_queue", "wide16", "autotune", "side_readout", "f16"):
+        for k in ("work_queue", "wide16", "autotune", "side_readout", "f16", "last_pass"):
             ctx.set_option(k, 1)
         ctx.set_option("long_helps", 0)
         opts = {}
@@ -77,6 +77,7 @@ def main(budget=300.0, seed=1):
         if rng.random() < 0.2: opts["long_helps"] = 1
         if rng.random() < 0.3: opts["f16"] = int(rng.choice([0, 2]))   # int16 cells only / f16 cells whatever the score bound
         if rng.random() < 0.2: opts["autotune"] = 0
+        if rng.random() < 0.2: opts["last_pass"] = 0   # every pass of a long query with the same columns per lane
         if rng.random() < 0.15: opts["wide16"] = 0
         if rng.random() < 0.25:   # multi-pass launches cut into segments of consecutive pairs (never shorter than a pair)
             opts["segment_blocks"] = int((max(lens) + 5) // 4 * rng.choice([1, 2, 7]) + rng.integers(0, 3))

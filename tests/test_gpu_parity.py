@@ -16,7 +16,7 @@ def _setup(ctx, g):
 
 
 OPTIONS = ("force_bits", "engine", "cols_per_wave", "max_waves", "group_lanes", "long_split", "workgroups", "segment_blocks")
-DEFAULT_ON = ("work_queue", "wide16", "f16", "qq")
+DEFAULT_ON = ("work_queue", "wide16", "f16", "qq", "last_pass")
 DEFAULT_OFF = ("long_helps",)
 
 
@@ -983,6 +983,40 @@ def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones):
             assert st["n_rescored"] == int((want[part] >= 4096).sum()) + int((want >= 65535).sum())
         else:
             assert st["cell_form"] == 2 and st["n_rescored"] == int((want >= 4096).sum()), st
+    db.close()
+    _reset_options(ctx)
+    ctx.set_option("autotune", 1)
+
+
+@pytest.mark.parametrize("geom,last", [((32, 16), 28), ((23, 32), 2), ((16, 64), 15), ((31, 16), 2), ((25, 16), 13)])
+@pytest.mark.parametrize("f16", [0, 2])
+def test_last_pass_has_its_own_geometry(swg, ctx, geom, last, f16):
+    """A query of several passes: the last pass runs the instantiation with the fewest columns per lane that cover
+    what is left of the query (3000 columns as 5 x 512 + 28 x 16, as 4 x 736 + 2 x 32, as 7 x 400 + 13 x 16 ...) -- a
+    different kernel and profile layout from the other passes', the same scores (reference-produced golden, lq 3000),
+    with the option off too."""
+    g = load_golden("blosum62_lq3000")
+    _setup(ctx, g)
+    K, G = geom
+    lq = len(g["query"])
+    npass = -(-lq // (K * G))
+    want_last = -(-(lq - (npass - 1) * K * G) // G)
+    want_last = max(2, want_last)
+    ctx.set_option("autotune", 0)
+    ctx.set_option("engine", 2)
+    ctx.set_option("cols_per_wave", K)
+    ctx.set_option("group_lanes", G)
+    ctx.set_option("max_waves", 4)
+    ctx.set_option("long_split", -1)
+    ctx.set_option("f16", f16)
+    db = swg.Database(g["flat"], g["offsets"]).upload(ctx)
+    for on in (1, 0):
+        ctx.set_option("last_pass", on)
+        scores, _, st = ctx.search(db, k=5)
+        assert np.array_equal(scores, _truth(g)) and np.array_equal(scores, g["ref16"].astype(np.int32)), (geom, on, st)
+        assert st["passes"] == npass and st["cols_per_wave"] == K and st["group_lanes"] == G, st
+        assert st["last_pass_cols"] == (want_last if on and want_last < K else 0), (st, want_last)
+        assert not on or st["last_pass_cols"] == last
     db.close()
     _reset_options(ctx)
     ctx.set_option("autotune", 1)
