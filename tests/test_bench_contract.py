@@ -37,10 +37,17 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["unit"] == "GCUPS" and d["data"] == "synthetic"
     assert d["config"]["workload"].startswith("config 3:") and d["config"]["n_seqs"] == 570000
     _check_block(d)
-    assert set(d["configs"]) == {"2", "3", "4", "5"}
+    assert set(d["configs"]) == {"2", "3", "4", "5", "5_stress"}
     for k, b in d["configs"].items():
-        assert b["config"]["workload"].startswith("config %s:" % k)
+        assert b["config"]["workload"].startswith("config %s:" % k.replace("_stress", " (stress variant)"))
         _check_block(b)
+    # the stress variant of config 5: every one of its 100 000 sequences re-scored in the `rescore` leg
+    cs = d["configs"]["5_stress"]
+    assert cs["config"]["n_seqs"] == 100000 and cs["rescore"]["n_rescored"] == 100000 and cs["rescore"]["top_k_equals_main_leg"]
+    # both 16-bit forms in config 5's search, each part with its own share of the cells and of the issue peak
+    r5 = d["configs"]["5"]["roofline"]["binding_roof"]
+    assert d["configs"]["5"]["dtype"] == "f16+int16" and abs(r5["cells_share"] + r5["other_kernel"]["cells_share"] - 1.0) < 1e-3
+    assert 0.5 < r5["frac_of_issue_peak"] <= 1.0 and 0.5 < r5["other_kernel"]["frac_of_issue_peak"] <= 1.0
     assert d["configs"]["3"]["value"] == d["value"]
     # config 5 as BASELINE names it: one GPU's share of the 10M-sequence shape, and a leg that really re-scores
     c5 = d["configs"]["5"]
