@@ -399,7 +399,9 @@ def plan_of(last):
             "cells": {0: "packed int16", 1: "packed int16, wide form (to 65535)",
                       2: "packed f16, three-operand maxima (exact below 4096; above: int32 re-score)",
                       4: "packed f16 for sequences under %d rows, wide int16 form for the longer ones "
-                         "(what the f16 cells flag all the same: the wide form again)" % last["split_rows"]}.get(last["cell_form"])
+                         "(what the f16 cells flag all the same: the wide form again)" % last["split_rows"],
+                      5: "packed f16 for sequences under %d rows, packed int16 for the longer ones "
+                         "(from 32767 up: int32 re-score)" % last["split_rows"]}.get(last["cell_form"])
                      if last["path_bits"] == 16 else "int32",
             "streams": last["streams"], "long_pairs": last["long_pairs"],
             "long_cols_per_lane": last["long_cols_per_lane"], "long_streams": last["long_streams"],
@@ -433,7 +435,7 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     # (counters are collected per configuration and cell form as bench.py --config C runs it; a leg without a
     # measurement of its own gets null rather than a neighbour's figure)
     table, source = _traffic_table(a.traffic_json)
-    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {1: "_wide", 2: "_f16", 4: "_split"}.get(form, "") if q16 else "_int32")
+    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {1: "_wide", 2: "_f16", 4: "_split", 5: "_split16"}.get(form, "") if q16 else "_int32")
     traffic = table.get(key, {}).get("hbm_bytes_per_launch")
     # The binding roof is VALU issue, reported beside the (by construction tiny) HBM fraction: one wave64 packed
     # instruction per SIMD every 4 cycles (16 lanes per cycle) at 2.4 GHz.  Instructions per cell: 5 for the packed
@@ -441,7 +443,7 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     # 12 for the term-by-term int32 kernels.  An isolated stream of packed instructions measures 4.4-4.56 cycles
     # with 4 waves per SIMD (tools/valu_rate.hip); the fill kernels get to 4.05.
     split = None
-    if q16 and form == 4:
+    if q16 and form in (4, 5):
         # both 16-bit forms in one search: half of the launches ran the long sequences on the wide form, the other
         # half -- the dominant kernel, which this object describes -- the rest on the f16 cells; the library times
         # the two parts apart (swg_stats.fill_f16_ms) and says how many cells each took
@@ -450,7 +452,7 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
         wide_ms, wide_cells = step_fill_ms * (1.0 - share), cells_local - cells_f16
         n_f16 = max(1, int(last["fill_f16_launches"]))
         n_wide = max(1, launches - n_f16)
-        split = {"kernel": "swg_diag_dyn_kernel<K=%d,wide>" % last["cols_per_wave"], "launches_per_step": n_wide,
+        split = {"kernel": "swg_diag_dyn_kernel<K=%d,%s>" % (last["cols_per_wave"], "wide" if form == 4 else "int16"), "launches_per_step": n_wide,
                  "kernel_ms": round(wide_ms / n_wide, 4), "cells_share": round(wide_cells / max(1, cells_local), 4),
                  "kernel_gcups": round(wide_cells / (wide_ms * 1e-3) / 1e9, 2), "instr_per_cell": 5.0}
         bytes_alg = int(int(last["bytes_alg"]) * (cells_f16 / max(1, cells_local))) // n_f16
@@ -473,7 +475,7 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     else:
         ops_per_cell = 5.0 if last["path_bits"] == 16 else 12.0
         kname = "swg_fill_kernel<CellsI%d>" % last["path_bits"]
-    if q16 and form != 4 and int(last["last_pass_cols"]) > 0 and int(last["passes"]) > 1:
+    if q16 and form not in (4, 5) and int(last["last_pass_cols"]) > 0 and int(last["passes"]) > 1:
         # the last pass of a long query runs an instantiation with fewer columns per lane: kernel_ms is the mean over
         # all the launches of one search's fill, i.e. rocprofv3's two per-kernel averages weighted by their calls
         per_pass = launches // int(last["passes"])
@@ -497,7 +499,7 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
         split["frac_of_issue_peak"] = round(split["kernel_gcups"] / split["peak_gcups_issue"], 4)
         roofline["binding_roof"]["cells_share"] = round(1.0 - split["cells_share"], 4)
         roofline["binding_roof"]["other_kernel"] = split
-    dtype = ("f16" if form == 2 else "f16+int16" if form == 4 else "int16") if last["path_bits"] == 16 else "int32"
+    dtype = ("f16" if form == 2 else "f16+int16" if form in (4, 5) else "int16") if last["path_bits"] == 16 else "int32"
     return roofline, dtype
 
 

@@ -66,7 +66,7 @@ typedef struct swg_stats {
     uint64_t cells_padded;  /* cells actually computed (bin + strip padding) */
     uint64_t bytes_alg;     /* algorithmic HBM bytes of the fill */
     uint64_t n_rescored;    /* sequences that reached the ceiling of the cells they ran on and were run again on wider
-                             * ones (cell_form 2: those the f16 cells flagged; 4: those plus the wide form's) */
+                             * ones (cell_form 2: those the f16 cells flagged; 4, 5: those plus the int16 cells') */
     double fill_ms;         /* 16-bit fill kernel (or the int32 fill when forced) */
     double rescore_ms;      /* overflow collection + int32 re-score */
     double topk_ms;         /* device top-K selection */
@@ -99,12 +99,13 @@ typedef struct swg_stats {
      * QUERIES per lane against one sequence instead of two sequences against one query, 4 both of the 16-bit
      * forms in one search: a query long enough to score beyond 32767 runs the sequences that could reach the f16
      * cells' ceiling -- those of split_rows rows or more -- on the wide form and everything shorter on the f16
-     * cells (what those flag all the same is run again on the wide form, so the scores are exact either way) */
+     * cells (what those flag all the same is run again on the wide form, so the scores are exact either way), 5 the same
+     * with option wide16 = 0: the long sequences on the plain int16 cells, everything from 32767 up re-scored in int32 */
     int32_t cell_form;
-    int32_t split_rows;     /* cell_form 4: the length from which sequences took the wide form; else 0 */
-    int32_t fill_f16_launches; /* cell_form 4: how many of fill_launches ran the f16 cells; else 0 */
-    double fill_f16_ms;     /* cell_form 4: the part of fill_ms spent on the f16 cells; else 0 */
-    uint64_t cells_f16;     /* cell_form 4: the real cells computed on the f16 cells; else 0 */
+    int32_t split_rows;     /* cell_form 4, 5: the length from which sequences took the int16 cells; else 0 */
+    int32_t fill_f16_launches; /* cell_form 4, 5: how many of fill_launches ran the f16 cells; else 0 */
+    double fill_f16_ms;     /* cell_form 4, 5: the part of fill_ms spent on the f16 cells; else 0 */
+    uint64_t cells_f16;     /* cell_form 4, 5: the real cells computed on the f16 cells; else 0 */
     int32_t last_pass_cols; /* diagonal engine, several passes: columns per lane of the last pass when it has a geometry of
                              * its own (fewer than cols_per_wave); else 0 */
 } swg_stats;

@@ -737,7 +737,7 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
                                      (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols, pl.K, kp, 4,
                                      SWG_LDS_SWIZZLE ? pl.G : 0, diag_class_form(ctx, db, pl) == 2, tail, pl.last_K, kp_last, qcol0);
         if (rc != SWG_OK) return rc;
-        if (pl.wide && pl.f16_from > 0) { // both forms in this class: the f16 cells' profile of the same geometry
+        if (pl.f16_from > 0) { // both forms in this class: the f16 cells' profile of the same geometry
             rc = ensure_profile_cols(ctx, 7, ncols, 2, (1ull << 55) | ((uint64_t)pl.K << 40) | ((uint64_t)pl.G << 32) | (uint64_t)ncols,
                                      pl.K, kp, 4, SWG_LDS_SWIZZLE ? pl.G : 0, 1, tail, pl.last_K, kp_last, qcol0);
             if (rc != SWG_OK) return rc;
@@ -839,7 +839,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             // take all their passes on the wide form, then the rest theirs on the f16 cells, the same geometry
             // throughout; ev[5] between the two parts tells their times apart.
             const uint32_t class_begin = q.q_begin, class_end = q.q_end;
-            const bool split = c == 0 && wk.n_classes == 1 && form == 1 && pl.f16_from > class_begin && pl.f16_from < class_end;
+            const bool split = c == 0 && wk.n_classes == 1 && form != 2 && pl.f16_from > class_begin && pl.f16_from < class_end;
             bool first_launch = true;
             int launches = 0, f16_launches = 0;
             for (int part = 0; part < (split ? 2 : 1); ++part) {
@@ -1703,7 +1703,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         q32_ok = db->ptok.ok && q32_list_plan(ctx, lq, 1, &probe) &&
                  (probe.plan[0].npass == 1 || db->ptok.total_blocks < (1ull << 28)); // (32-bit edge indices)
     }
-    // A query long enough to score beyond 32767 gets the wide form -- but only a sequence that is long itself can get
+    // A query long enough to score beyond 32767 gets the wide form (wide16 = 0: plain int16 cells and the int32
+    // re-score from 32767) -- but only a sequence that is long itself can get
     // anywhere near: an exact copy of a stretch of the query scores qbound / lq per row on average, so one of fewer
     // than 4096 * lq / qbound rows stays below the f16 cells' ceiling even then.  Those (most of a protein database:
     // 730 rows with BLOSUM62) take the f16 cells, 8.5 instructions per column pair instead of 10, in launches of
@@ -1711,7 +1712,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // cells flag all the same is run again on the wide form like any other flagged pair, so results do not depend on it.
     uint32_t split_at = 0, split_rows = 0;
     uint64_t split_residues = 0;
-    if (!use_f16 && wide && use_diag && ctx->opt_f16 == 1 && db->f16_veto_epoch != ctx->epoch && -go <= 2048 && -ge <= 2048 &&
+    if (!use_f16 && bits == 16 && score_bound >= 32767ull && use_diag && ctx->opt_f16 == 1 && db->f16_veto_epoch != ctx->epoch && -go <= 2048 && -ge <= 2048 &&
         wk.n_classes == 1 && diag_class_is_dynamic(ctx, db, wk.plan[0]) && !db->tokens_only && qbound > 0) {
         swg_db *mdb = const_cast<swg_db *>(db);
         const uint32_t rows = (uint32_t)std::min<uint64_t>((4096ull * lq + qbound - 1) / qbound, 1u << 30);
@@ -1756,7 +1757,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
     // what the f16 cells flag is run again on int16 cells (the wide form if scores may pass 32767); only what
     // saturates those too needs the int32 kernel
-    const bool rerun_wide = (use_f16 && score_bound >= 32767ull && ctx->opt_wide != 0) || split_at != 0u;
+    const bool rerun_wide = (use_f16 && score_bound >= 32767ull && ctx->opt_wide != 0) || (split_at != 0u && wide);
     if (use_f16 && score_bound >= (rerun_wide ? 65535ull : 32767ull) && !q32_ok) use_f16 = false;
     for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].f16 = use_f16 ? 1 : 0;
     const bool some_f16 = use_f16 || split_at != 0u; // some pairs run on the f16 cells: their flags are collected and re-run
@@ -2068,7 +2069,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     st.path_bits = bits;
     st.cell_form = use_diag ? diag_class_form(ctx, db, dpl) : 0;
     if (use_diag && dpl.f16_from != 0u) {
-        st.cell_form = 4;
+        st.cell_form = dpl.wide ? 4 : 5;
         st.n_rescored = (uint64_t)h_counters[16] + h_counters[1]; // flagged by the f16 cells + saturated on the wide form
         st.split_rows = (int32_t)S->split_rows;
         st.fill_f16_launches = S->fill_f16_launches;

@@ -930,8 +930,8 @@ def test_config5_every_sequence_similar(swg, ctx, orc):
 
 
 @pytest.mark.parametrize("opts", [{}, {"segment_blocks": 3000}, {"cols_per_wave": 24, "group_lanes": 32, "max_waves": 4, "long_split": -1}])
-@pytest.mark.parametrize("long_ones", [True, False])
-def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones):
+@pytest.mark.parametrize("long_ones,wide16", [(True, 1), (False, 1), (True, 0)])
+def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones, wide16):
     """A query that can score beyond 32767 (wide form) against a database of mostly short sequences: those under
     4096 * lq / qbound rows run on the f16 cells, the longer ones on the wide form, in launches of their own per pass
     (swg_stats.cell_form 4).  The threshold is an expectation, so the database also holds what defeats it: runs of
@@ -939,7 +939,8 @@ def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones):
     wide form score again; near-copies of the whole query (beyond 32767, on the wide form from the start).  Without any
     long sequence (long_ones False) the whole search runs on the f16 cells and what they flag on the wide form.  All
     scores against the oracle, twice (the second search plans the re-run from what the first one saw), also with the
-    passes cut into segments and with a forced geometry."""
+    passes cut into segments and with a forced geometry.  wide16 = 0: the long part on plain int16 cells, everything
+    from 32767 up -- the f16 part's flagged pairs that saturate their int16 re-run too -- re-scored in int32."""
     sc = swg.load_scoring("BLOSUM62")
     # (an entry no sequence here uses, so that "longest sequence x largest entry" does not cap the score bound below
     # 32767 when every sequence is short: the search without long ones must still plan for the wide range)
@@ -970,6 +971,7 @@ def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones):
     ctx.set_query(q)
     _reset_options(ctx)
     ctx.set_option("autotune", 0)
+    ctx.set_option("wide16", wide16)
     for k, v in opts.items():
         ctx.set_option(k, v)
     db = swg.Database(flat, off).upload(ctx)
@@ -979,8 +981,8 @@ def test_both_16bit_forms_in_one_search(swg, ctx, orc, opts, long_ones):
         assert hits == orc.topk(want, 20) and st["passes"] > 1
         if long_ones:
             part = _f16_part(np.asarray(lens), st["split_rows"])
-            assert st["cell_form"] == 4 and 500 < st["split_rows"] < 560 and st["cells_f16"] == len(q) * int(np.asarray(lens)[part].sum()), st
-            assert st["n_rescored"] == int((want[part] >= 4096).sum()) + int((want >= 65535).sum())
+            assert st["cell_form"] == (4 if wide16 else 5) and 500 < st["split_rows"] < 560 and st["cells_f16"] == len(q) * int(np.asarray(lens)[part].sum()), st
+            assert st["n_rescored"] == int((want[part] >= 4096).sum()) + int((want >= (65535 if wide16 else 32767)).sum())
         else:
             assert st["cell_form"] == 2 and st["n_rescored"] == int((want >= 4096).sum()), st
     db.close()
@@ -1050,7 +1052,7 @@ def test_titin_sized_query(swg, ctx, orc, wide16):
         got, hits, st = ctx.search(db, k=8)
         assert np.array_equal(got, want), (attempt, st, np.nonzero(got != want)[0][:8])
         assert hits == orc.topk(want, 8) and st["passes"] >= 18 and st["path_bits"] == 16
-        assert st["cell_form"] == (4 if wide16 else 0), st
+        assert st["cell_form"] == (4 if wide16 else 5), st   # (both forms; the long part on the wide form / on plain int16 cells)
     db.close()
     _reset_options(ctx)
     ctx.set_option("autotune", 1)
