@@ -33,7 +33,9 @@ ARCH = "gfx950"
 # within that budget the default strategy left the K=32 multi-pass kernel 14-19 registers short
 # (spills inside the row loop), max-ilp fits it in 158 with no spill.  Measured on one box, same
 # source: config 4 6933 -> 7178 GCUPS, config 5 6505 -> 6512, config 2 6284 -> 6283, config 3
-# 7150 -> 7180 (profiles/r02_sched_strategy_ab.txt).  The option is read by the AMDGPU target
+# 7150 -> 7180 (profiles/r02_sched_strategy_ab.txt); round 3's kernels (f16 cells), alternating the two builds on
+# one box: config 4 8240 -> 8460, config 5 7470 -> 7870, configs 2 and 3 level (profiles/r03_sched_strategy_ab.txt).
+# The option is read by the AMDGPU target
 # only; the host half of the compile ignores it.
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt",
                 "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
