@@ -176,6 +176,7 @@ _sig("swg_synth_db_shard", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_dou
 _sig("swg_synth_free", None, [_vp])
 # test hook, declared in csrc/swg_host_internal.h (not part of the public ABI)
 _sig("swg_debug_plan", C.c_int, [_vp, C.c_size_t, C.c_int, _vp])
+_sig("swg_debug_split", C.c_int, [_vp, C.c_size_t, C.c_uint64, _vp])
 _sig("swg_debug_pair_tokens", C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)])
 
 
@@ -378,10 +379,18 @@ class Database:
 
     def debug_plan(self, lq, n_cu=256):
         """Test hook: the cost model's first choice for this database and a query of lq residues (no device needed)."""
-        out = np.zeros(12, dtype=np.int32)
+        out = np.zeros(13, dtype=np.int32)
         _check(lib.swg_debug_plan(self.handle, lq, n_cu, out.ctypes.data_as(_vp)))
-        keys = ("classes", "K", "G", "W", "passes", "workgroups", "long_pairs", "long_K", "long_G", "long_W", "long_workgroups", "est_us")
+        keys = ("classes", "K", "G", "W", "passes", "workgroups", "long_pairs", "long_K", "long_G", "long_W", "long_workgroups", "est_us",
+                "last_pass_cols")
         return dict(zip(keys, (int(v) for v in out)))
+
+    def debug_split(self, lq, qbound):
+        """Test hook: the both-forms cut (a query of lq columns that can score qbound at best) -> rows, first pair of the
+        f16 part in the sorted order, residues of the f16 part (no device needed)."""
+        out = np.zeros(3, dtype=np.uint64)
+        _check(lib.swg_debug_split(self.handle, lq, qbound, out.ctypes.data_as(_vp)))
+        return {"rows": int(out[0]), "first_pair": int(out[1]), "residues_f16": int(out[2])}
 
     def debug_pair_tokens(self, ctx, from_host):
         """Test hook: the pair-token image (uint32 dwords) built on the device or by the host builder."""

@@ -1714,18 +1714,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     uint64_t split_residues = 0;
     if (!use_f16 && bits == 16 && score_bound >= 32767ull && use_diag && ctx->opt_f16 == 1 && db->f16_veto_epoch != ctx->epoch && -go <= 2048 && -ge <= 2048 &&
         wk.n_classes == 1 && diag_class_is_dynamic(ctx, db, wk.plan[0]) && !db->tokens_only && qbound > 0) {
-        swg_db *mdb = const_cast<swg_db *>(db);
-        const uint32_t rows = (uint32_t)std::min<uint64_t>((4096ull * lq + qbound - 1) / qbound, 1u << 30);
-        if (mdb->split_rows != rows) { // (per database and threshold: a binary search and one pass over the lengths)
-            const size_t n = db->lens.size();
-            const size_t first_short = (size_t)(std::partition_point(db->lens.begin(), db->lens.end(), [rows](uint32_t l) { return l >= rows; }) -
-                                                db->lens.begin());
-            mdb->split_rows = rows;
-            mdb->split_pair = (uint32_t)((first_short + 1) / 2); // (a pair with one long member is a long pair)
-            uint64_t sum = 0;
-            for (size_t i = std::min(n, (size_t)mdb->split_pair * 2); i < n; ++i) sum += db->lens[i];
-            mdb->split_residues = sum;
-        }
+        const uint32_t rows = swg_split_rows(lq, qbound);
+        swg_db_split_at(const_cast<swg_db *>(db), rows); // (per database and length: a binary search and one pass over the lengths)
         const uint32_t cut = std::max<uint32_t>(db->split_pair, (uint32_t)wk.pair_begin[0]);
         if (cut <= wk.pair_begin[0] && (score_bound < 65535ull || q32_ok)) {
             // nothing long in this database: the f16 cells for all of it (what they flag: the wide form, as below)
@@ -1746,14 +1736,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         pl.last_variant = -1;
         pl.last_K = 0;
         if (!use_diag || wk.n_classes != 1 || pl.npass < 2 || !diag_class_is_dynamic(ctx, db, pl) || ctx->opt_last_pass == 0) continue;
-        const size_t rest = lq - (size_t)(pl.npass - 1) * pl.G * pl.K;
-        const int need = (int)((rest + pl.G - 1) / pl.G);
-        int best = -1, bestK = pl.K;
-        for (int v = 0; v < swg_num_diag_variants(); ++v) {
-            const SwgKernelInfo info = swg_diag_variant_info(v);
-            if (info.K >= need && info.K < bestK && pl.W <= info.max_waves) best = v, bestK = info.K;
-        }
-        if (best >= 0) pl.last_variant = best, pl.last_K = bestK;
+        if (!swg_plan_last_pass(pl, lq, &pl.last_variant, &pl.last_K)) pl.last_variant = -1, pl.last_K = 0;
     }
     // what the f16 cells flag is run again on int16 cells (the wide form if scores may pass 32767); only what
     // saturates those too needs the int32 kernel

@@ -418,10 +418,64 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
     return 0;
 }
 
+// Several passes of G*K columns each leave the last one partly empty (3000 columns in 6 passes of 512: 72 of them, 2.3 %
+// of the work): it runs the instantiation with the fewest columns per lane that cover what is left.  Returns false when
+// there is nothing to gain (one pass; the rest needs all K columns; no instantiation takes the plan's workgroup size).
+bool swg_plan_last_pass(const SwgDiagPlan &pl, size_t lq, int *variant, int *K)
+{
+    if (pl.npass < 2 || pl.G <= 0 || pl.K <= 0 || lq <= (size_t)(pl.npass - 1) * pl.G * pl.K) return false;
+    const size_t rest = lq - (size_t)(pl.npass - 1) * pl.G * pl.K;
+    const int need = (int)((rest + pl.G - 1) / pl.G);
+    int best = -1, bestK = pl.K;
+    for (int v = 0; v < swg_num_diag_variants(); ++v) {
+        const SwgKernelInfo info = swg_diag_variant_info(v);
+        if (info.K >= need && info.K < bestK && pl.W <= info.max_waves) best = v, bestK = info.K;
+    }
+    if (best < 0) return false;
+    *variant = best;
+    *K = bestK;
+    return true;
+}
+
+// Both 16-bit forms in one search (swg_search_begin): the length from which a sequence can reach the f16 cells' ceiling
+// as an exact copy of a stretch of the query -- such a copy scores qbound / lq per row on average, qbound being the
+// query's best possible total --, and where that length cuts the sorted pair order (kept per database and length).
+uint32_t swg_split_rows(size_t lq, uint64_t qbound)
+{
+    if (qbound == 0) return 0u;
+    return (uint32_t)std::min<uint64_t>((4096ull * lq + qbound - 1) / qbound, 1u << 30);
+}
+
+void swg_db_split_at(swg_db *db, uint32_t rows)
+{
+    if (db->split_rows == rows) return;
+    const size_t n = db->lens.size();
+    const size_t first_short = (size_t)(std::partition_point(db->lens.begin(), db->lens.end(), [rows](uint32_t l) { return l >= rows; }) -
+                                        db->lens.begin());
+    db->split_rows = rows;
+    db->split_pair = (uint32_t)((first_short + 1) / 2); // (a pair with one long member is a long pair)
+    uint64_t sum = 0;
+    for (size_t i = std::min(n, (size_t)db->split_pair * 2); i < n; ++i) sum += db->lens[i];
+    db->split_residues = sum;
+}
+
+// Test hook (not part of the public ABI): the both-forms cut of a packed database for a query of lq columns whose best
+// possible total is qbound.  out[0..2] = rows, first pair of the f16 part, residues of the f16 part.
+extern "C" int swg_debug_split(swg_db *db, size_t lq, uint64_t qbound, uint64_t *out)
+{
+    if (!db || !out || lq == 0 || qbound == 0) return SWG_ERR_ARG;
+    const uint32_t rows = swg_split_rows(lq, qbound);
+    swg_db_split_at(db, rows);
+    out[0] = rows;
+    out[1] = db->split_pair;
+    out[2] = db->split_residues;
+    return SWG_OK;
+}
+
 // Test hook (not part of the public ABI, declared in swg_host_internal.h): the cost model's first choice
 // for a packed database and a query length on a device of n_cu compute units, without a device.
-// out[0..11] = classes, K, G, W, passes, workgroups, long pairs, long K, long G, long W, long workgroups,
-// estimated microseconds.
+// out[0..12] = classes, K, G, W, passes, workgroups, long pairs, long K, long G, long W, long workgroups,
+// estimated microseconds, columns per lane of the last pass (0: as the other passes).
 extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *out)
 {
     if (!db || !out || lq == 0 || n_cu <= 0) return SWG_ERR_ARG;
@@ -433,8 +487,10 @@ extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *ou
     }
     const SwgDiagPlan &b = wk.plan[0], &l = wk.plan[1];
     const bool two = wk.n_classes == 2;
-    const int32_t v[12] = {wk.n_classes, b.K, b.G, b.W, b.npass, b.workgroups, two ? (int32_t)(wk.pair_end[1] - wk.pair_begin[1]) : 0,
-                           two ? l.K : 0, two ? l.G : 0, two ? l.W : 0, two ? l.workgroups : 0, (int32_t)(b.est_ms * 1e3)};
+    int last_variant = -1, last_K = 0;
+    if (two || !swg_plan_last_pass(b, lq, &last_variant, &last_K)) last_K = 0;
+    const int32_t v[13] = {wk.n_classes, b.K, b.G, b.W, b.npass, b.workgroups, two ? (int32_t)(wk.pair_end[1] - wk.pair_begin[1]) : 0,
+                           two ? l.K : 0, two ? l.G : 0, two ? l.W : 0, two ? l.workgroups : 0, (int32_t)(b.est_ms * 1e3), last_K};
     memcpy(out, v, sizeof v);
     return SWG_OK;
 }

@@ -259,6 +259,11 @@ int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
 void swg_db_release_device(swg_db *db);
 // test hook: the pair-token image as the device built it, or as the host restatement builds it
 extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *out);
+extern "C" int swg_debug_split(swg_db *db, size_t lq, uint64_t qbound, uint64_t *out);
+// decisions swg_search_begin makes on top of the planner's geometry (host only: swg_diag_host.cpp)
+bool swg_plan_last_pass(const SwgDiagPlan &pl, size_t lq, int *variant, int *K);
+uint32_t swg_split_rows(size_t lq, uint64_t qbound);
+void swg_db_split_at(swg_db *db, uint32_t rows);
 extern "C" int swg_debug_pair_tokens(swg_ctx *ctx, swg_db *db, int from_host, uint32_t *out, size_t cap_dwords,
                                      size_t *n_dwords);
 

@@ -41,12 +41,57 @@ def test_config3_headline(swg):
 def test_config4_share_six_passes(swg):
     p = _plan(swg, 0x5EED0004, 1250000, 3000)
     assert (p["classes"], p["K"], p["G"], p["W"], p["passes"], p["workgroups"]) == (1, 32, 16, 4, 6, 768), p
+    assert p["last_pass_cols"] == 28, p         # 3000 = 5 x 512 + 440: the last pass with 28 columns per lane (448)
 
 
 def test_config5_long_query_near_copies(swg):
     # the planted 8 200-row pairs are the chain of every pass: 64 lanes each, two wavefronts per SIMD
     p = _plan(swg, 0x5EED0005, 100000, 8192, fraction=0.01, subst=0.05)
     assert (p["classes"], p["K"], p["G"], p["W"], p["passes"]) == (1, 32, 64, 8, 4), p
+    assert p["last_pass_cols"] == 0, p          # 8192 = 4 x 2048: nothing left over
+
+
+def test_last_pass_columns(swg):
+    """The last pass of a query of several passes covers what is left with the fewest columns per lane (a single pass
+    and a two-class plan have none of their own)."""
+    flat, off = swg.synth_db(0x5EED0003, 200000)
+    db = swg.Database(flat, off)
+    try:
+        for lq in (367, 500, 2000, 2300, 3000, 4000, 5000, 6000, 8192, 8200):
+            p = db.debug_plan(lq)
+            cover = p["K"] * p["G"]
+            if p["passes"] == 1 or p["classes"] == 2:
+                assert p["last_pass_cols"] == 0, (lq, p)
+                continue
+            rest = lq - (p["passes"] - 1) * cover
+            assert 0 < rest <= cover, (lq, p)
+            need = max(2, -(-rest // p["G"]))
+            assert p["last_pass_cols"] == (need if need < p["K"] else 0), (lq, p, need)
+    finally:
+        db.close()
+
+
+def test_both_forms_cut(swg):
+    """The length from which a sequence takes the int16 cells in a search that runs both forms: 4096 * lq / qbound rows
+    (qbound: the query's best possible total), and where it cuts the sorted order -- pairs (2i, 2i+1) by rank, a pair
+    with one long member being a long pair."""
+    sc = swg.load_scoring("BLOSUM62")
+    tab = sc.table().astype(np.int64)
+    lq = 8192
+    q = swg.synth_query(0x5EED0005, lq)
+    flat, off, planted = swg.synth_db(0x5EED0005, 20000, query=q, fraction=0.01, subst=0.05)
+    qbound = int(tab[q.astype(np.int64)][:, 1:].max(axis=1).sum())
+    db = swg.Database(flat, off)
+    try:
+        cut = db.debug_split(lq, qbound)
+    finally:
+        db.close()
+    rows = -(-4096 * lq // qbound)
+    assert cut["rows"] == rows and 700 < rows < 900, (cut, qbound)
+    lens = np.sort(np.diff(off.astype(np.int64)))[::-1]
+    n_long = int((lens >= rows).sum())
+    first = (n_long + 1) // 2
+    assert planted <= n_long < len(lens) // 2 and cut["first_pair"] == first and cut["residues_f16"] == int(lens[2 * first:].sum()), cut
 
 
 @pytest.mark.parametrize("lq,want", [(600, (1, 19, 32, 4, 1)), (800, (1, 25, 32, 12, 1)), (1000, (1, 32, 32, 12, 1)),
