@@ -1745,7 +1745,6 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     for (int c = 0; c < wk.n_classes; ++c) wk.plan[c].f16 = use_f16 ? 1 : 0;
     const bool some_f16 = use_f16 || split_at != 0u; // some pairs run on the f16 cells: their flags are collected and re-run
     const int32_t ceiling = use_f16 ? 4096 : wide ? 65535 : 32767;
-    const SwgDiagPlan &dpl = wk.plan[0];
     const bool may_saturate = bits == 16 && (score_bound >= (uint64_t)ceiling || split_at != 0u);
     if (may_saturate) {
         const long keep_cols = ctx->opt_cols;

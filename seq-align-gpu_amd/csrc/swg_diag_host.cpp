@@ -329,7 +329,6 @@ static uint64_t write_pair_tokens(const swg_db *db, size_t p, uint32_t *t)
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
                            uint32_t streams_per_wg, SwgDiagLayout *L)
 {
-    const size_t n_slots = (size_t)db->n_bins * SWG_BIN;
     const size_t n_pairs = (size_t)(pair_end - pair_begin);
     L->pair_begin = pair_begin;
     L->pair_end = pair_end;
