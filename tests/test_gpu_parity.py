@@ -840,6 +840,19 @@ def test_randomised_soak():
     assert fuzz.main(30.0, 11) == 0
 
 
+def test_randomised_soak_of_query_batches():
+    """tests/fuzz_multi_gpu.py for twenty seconds: random batches of queries (equal, mixed and several-pass lengths,
+    relatives planted, cell forms and two-queries-per-lane drawn, with and without the score array) through
+    swg_search_multi, every score and hit list against the int32 oracle."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_multi_gpu", os.path.join(ROOT, "tests", "fuzz_multi_gpu.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.main(20.0, 3) == 0
+
+
 def _db_with_empties(swg, seed, n, n_empty, max_len):
     """Random database with n_empty zero-length records mixed in at seeded positions."""
     flat, off = swg.synth_db(seed, n, min_len=1, max_len=max_len)
