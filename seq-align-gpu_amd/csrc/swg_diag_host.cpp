@@ -167,7 +167,6 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                 const size_t lds_wg = dynamic ? swg_diag_dyn_lds_bytes(info.K, G, W) : lds;
                 const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds_wg)));
                 const int eff_wps = std::min(4, wps * per_cu);
-                const double cps = kCyclesPerInstr[eff_wps];
                 const uint64_t spw = (uint64_t)W * NG;
                 const uint64_t hw_streams = (uint64_t)n_cu * per_cu * spw;
                 // (a long class beside a multi-pass queue launch would need its own edge buffers: not built)
@@ -186,8 +185,9 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                                                           : (uint64_t)(frac * rows_all / (double)streams0);
                         if (dynamic && opt_long_split <= 0) {
                             // longest pair a fair-share wavefront finishes within the whole search
-                            const double all_cycles = rows_all / NG * instr * cps / simds;
-                            thr = (uint64_t)((split == 3 ? 0.65 : 0.9) * all_cycles / (instr * cps * eff_wps));
+                            const double cps0 = kCyclesPerInstr[eff_wps]; // (a database that needs a long class fills its slots)
+                            const double all_cycles = rows_all / NG * instr * cps0 / simds;
+                            thr = (uint64_t)((split == 3 ? 0.65 : 0.9) * all_cycles / (instr * cps0 * eff_wps));
                         }
                         thr = std::max<uint64_t>(thr, 64);
                         if (longest <= thr) continue;
@@ -200,10 +200,16 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
                     const double rows_bulk = rows_all - rows_long;
                     uint64_t streams = std::max<uint64_t>(1, std::min<uint64_t>(hw_streams, (uint64_t)((double)n_bulk * copies)));
                     streams = (streams + spw - 1) / spw * spw;
+                    // A database of few pairs does not fill the wave slots the geometry allows: the chain's wavefront
+                    // shares its SIMD with as many others as the launch really has (a 300 000-row sequence among 400
+                    // short ones, lq 400: 64 lanes x 17 columns ranked first -- "one wavefront per SIMD" by its LDS
+                    // size, where 64 x 7 has the SIMD to itself just the same at half the instructions per row).
+                    const int eff = std::max(1, std::min(eff_wps, (int)std::ceil((double)(streams / spw) * W / simds)));
+                    const double cps = kCyclesPerInstr[eff];
                     // (a) throughput: SIMD-cycles of both classes over all SIMDs
                     double work = rows_bulk / NG * npass * instr * cps;
                     double crit = (std::max<double>(rows_bulk / streams, (double)longest_bulk) + G) * npass *
-                                  instr * cps * eff_wps;
+                                  instr * cps * eff;
                     uint64_t lstreams = 0;
                     SwgDiagPlan lp;
                     if (split) {
@@ -281,8 +287,13 @@ int swg_plan_diag_candidates(const swg_db *db, size_t lq, int n_cu, long opt_col
             }
         }
     }
-    std::stable_sort(cands->begin(), cands->end(),
-                     [](const SwgDiagWork &a, const SwgDiagWork &b) { return a.plan[0].est_ms < b.plan[0].est_ms; });
+    // (a positive long_split is a request: plans with the class it asks for rank before those without, whatever
+    // the model thinks of them -- when no pair is that long there are none, and the rest is ranked as usual)
+    const bool want_long = have_long && opt_long_split > 0;
+    std::stable_sort(cands->begin(), cands->end(), [want_long](const SwgDiagWork &a, const SwgDiagWork &b) {
+        const bool la = want_long && a.n_classes == 2, lb = want_long && b.n_classes == 2;
+        return la != lb ? la : a.plan[0].est_ms < b.plan[0].est_ms;
+    });
     return (int)cands->size();
 }
 

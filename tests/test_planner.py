@@ -114,3 +114,29 @@ def test_several_passes_with_wide_groups(swg, lq, want):
 def test_tiny_database_takes_the_widest_groups(swg):
     p = _plan(swg, 0x5EED0001, 1024, 128)
     assert p["G"] == 64 and p["passes"] == 1 and p["K"] * 64 >= 128, p
+
+
+def test_few_pairs_do_not_share_their_simd(swg):
+    """A database of few pairs does not fill the wave slots its geometry allows: the wavefront of the longest chain has
+    its SIMD to itself whatever the workgroup's LDS size, so the fewest columns per lane win (round 3: 64 lanes x 17
+    columns used to rank first for a 400-column query here -- one wavefront per SIMD by its LDS size -- and ran at half
+    the speed of 64 x 7 on the device)."""
+    lens = [300000, 120000, 7] + [int(v) for v in np.random.default_rng(3).integers(1, 600, size=400)]
+    seqs = [swg.synth_query(1000 + i, L) for i, L in enumerate(lens)]
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    db = swg.Database(np.concatenate(seqs), off)
+    try:
+        p = db.debug_plan(400)
+        assert (p["classes"], p["K"], p["G"], p["passes"]) == (1, 7, 64, 1), p
+        p = db.debug_plan(128)
+        assert (p["K"], p["G"], p["passes"]) == (2, 64, 1), p
+    finally:
+        db.close()
+    flat, off = swg.synth_db(0x5EED0001, 1024)            # config 1's shape: the estimate is the longest pair's chain
+    db = swg.Database(flat, off)
+    try:
+        p = db.debug_plan(128)
+        assert (p["classes"], p["K"], p["G"], p["passes"]) == (1, 2, 64, 1) and 250 < p["est_us"] < 700, p
+    finally:
+        db.close()
