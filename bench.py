@@ -12,11 +12,14 @@ its return code (`--spawn-dry-run` prints that command instead of running it).
 A step = one pass of the hot path (swg_search: int16 fill, saturation re-score when possible,
 top-K) over one resident synthetic database of the shapes of SURVEY 8d.
 
-One GPU, no --config: the JSON line's headline (`value`, `config`, `roofline`, `cpu_baseline`) is
-config 3, the largest single-GPU configuration of BASELINE.json (500 aa vs 570 000 sequences); the
-`configs` object holds one block of the same shape for each of configs 2, 3, 4 (one GPU's eighth of
-the 10M-sequence database) and 5, and `scaling_reference` is config 4's WHOLE 10M-sequence database
-searched on this one GPU -- the N = 1 point of the curve below.
+One GPU, no --config: the JSON line's headline (`value`, `config`, `roofline`, `cpu_baseline`, exactly
+--steps timed steps after --warmup untimed ones) is config 4's ONE 10M-sequence database (3000 aa query) searched
+WHOLE on this GPU through the sharded path with one shard -- the very workload `--gpus N` deals over N ranks, so
+value(N) / (N * value(1)) compares one workload with itself (it is the configuration BASELINE.json quotes its scaling
+target on, and it fits one GPU: 3.8 GB of residues).  The `configs` object holds one block of the same shape for each
+of configs 3 (round 3's headline), 2, 4 (one GPU's eighth of the 10M-sequence database), "4_relatives" (that share
+with a family of 30-70 %-identity relatives of the query: the f16 flag-and-re-run route, first search and steady
+state), 5 and 5's stress variant, and "4_whole" repeats the headline's block.
 
 N > 1 (one rank per GPU, torch.distributed over RCCL; SWG_BENCH_FORCE_DIST=1 rehearses the path with
 one rank): config 4 as ONE 10M-sequence database.  Every rank derives the same global length order,
@@ -65,13 +68,16 @@ CONFIGS = {
     5: dict(lq=8192, n=1250000, matrix="BLOSUM62", similar=0.01, n_full=10000000),
     # SURVEY 8d's stress variant of config 5: 100 000 sequences, every one a near-copy of the query (block "5_stress")
     6: dict(lq=8192, n=100000, matrix="BLOSUM62", similar=1.0),
+    # config 4's share with a family of relatives of the query in it (block "4_relatives"): a seeded 0.5 % of the
+    # sequences are copies of the 3000-aa query at 30-70 % identity, scores about 3 800 .. 10 000 -- above the f16
+    # cells' ceiling (4096), below int16's: the database on which the flag-and-re-run route is really taken
+    7: dict(lq=3000, n=1250000, matrix="BLOSUM62", similar=0.005, subst=0.3, subst_hi=0.7),
 }
 # BASELINE.json names config 5 "forcing 16->32-bit rescore": its block carries, beside the library's own choice
 # (the wide int16 form, exact to 65535: nothing left to re-score), the same database with plain int16 cells,
 # every flagged sequence re-scored by the int32 work-queue kernel.
 CONFIG_LEGS = {5: (("rescore", {"wide16": 0}),), 6: (("rescore", {"wide16": 0}),)}
-HEADLINE = 3            # largest single-GPU configuration of BASELINE.json
-SHARDED = 4             # the configuration N > 1 runs, as one database dealt by bins
+SHARDED = 4             # the configuration every --gpus N runs as ONE database dealt by bins (N = 1: the headline)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak
 METRIC = "GCUPS (DP cell updates/s) at 1/2/4/8 MI355X; bit-exact max scores vs CPU ref"
 
@@ -82,8 +88,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=0,
-                    help="0 (default): one GPU = configs 3 (headline), 2, 4-share, 5 and the 10M scaling reference; "
-                         "N GPUs = config 4 as one sharded database.  C: that configuration alone")
+                    help="0 (default): config 4 as ONE 10M-sequence database dealt over the N GPUs (N = 1: whole on the one GPU, "
+                         "the headline, followed by blocks for configs 3, 2, 4-share, 4 with relatives, 5).  C: that configuration alone")
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--max-waves", type=int, default=0)
@@ -111,8 +117,7 @@ def parse_args():
     ap.add_argument("--no-host-inclusive", action="store_true",
                     help="skip the one-off search from host buffers (PCIe-inclusive figure, reported beside value)")
     ap.add_argument("--no-verify", action="store_true", help="skip the top-K check against the oracle (outside the timed region)")
-    ap.add_argument("--no-scaling-reference", action="store_true",
-                    help="one GPU: skip the whole 10M-sequence config-4 database (the N = 1 point of the scaling curve)")
+    ap.add_argument("--no-scaling-reference", action="store_true", help="(accepted and ignored: the 10M-sequence database is the headline now)")
     ap.add_argument("--only-headline", action="store_true", help="one GPU: the headline configuration alone")
     ap.add_argument("--max-len", type=int, default=0, help="diagnostic: clamp the sequence lengths here (default 5000)")
     ap.add_argument("--uniform-len", type=int, default=0,
@@ -208,7 +213,8 @@ def make_context(env, q, sc):
     return ctx
 
 
-def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclusive_leg=False, cpu_leg=False, legs=()):
+def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclusive_leg=False, cpu_leg=False, legs=(),
+               first_search_leg=False):
     """One configuration: generate, pack, upload, warm up, time exactly `steps` steps between fences.
     sharded: the database is ONE global database dealt by bins over the ranks (strong scaling), else an
     independent database on this rank.  legs: ((name, {option: value}), ...): the same resident database timed
@@ -233,7 +239,8 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
         residues_total = sh["residues_total"]
     else:
         if cfg.get("similar"):
-            flat, off, _ = swg.synth_db(seed, n, query=q, fraction=cfg["similar"], subst=0.05)
+            flat, off, _ = swg.synth_db(seed, n, query=q, fraction=cfg["similar"], subst=cfg.get("subst", 0.05),
+                                        subst_hi=cfg.get("subst_hi"))
         elif a.uniform_len:
             flat, off = swg.synth_db(seed, n, min_len=a.uniform_len, max_len=a.uniform_len)
         elif a.max_len:
@@ -252,7 +259,9 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
     residues = int(db.residues)
     # setup, untimed like the upload: the first search of a query length plans the kernel geometry
     # for this database (and with --autotune times the best-ranked plans on this device)
-    ctx.search(db, want_scores=False, k=K)
+    t0 = time.perf_counter()
+    _, _, first_st = ctx.search(db, want_scores=False, k=K)
+    first_wall_ms = (time.perf_counter() - t0) * 1e3
 
     merger = TopKMerger(swg, K, env.rank, env.world, env.coll_device) if env.use_dist else None
     # Steps are software-pipelined two deep: search i+1 is queued on the GPU before the host finishes
@@ -338,10 +347,13 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
                         "%s, gaps %d/%d, global top-%d by one RCCL all-reduce" % (cnum, lq, n, env.world, cfg["matrix"], a.gapopen, a.gapextend, K))
         else:
             workload = ("config %s: 1 query (%d aa) vs %d-seq synthetic protein DB%s, %s, gaps %d/%d, top-%d"
-                        % ("5 (stress variant)" if cnum == 6 else str(cnum), lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], a.gapopen, a.gapextend, K))
+                        % ({6: "5 (stress variant)", 7: "4 (relatives)"}.get(cnum, str(cnum)), lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], a.gapopen, a.gapextend, K))
             if cnum == 4 and not n_override:
                 workload += " (one GPU's eighth of the 10M-sequence database)"
-            if cfg.get("similar"):
+            if cfg.get("subst_hi"):
+                workload += ", %g %% of the sequences relatives of the query (%d-%d %% identity)" % (
+                    100 * cfg["similar"], round(100 * (1 - cfg["subst_hi"])), round(100 * (1 - cfg["subst"])))
+            elif cfg.get("similar"):
                 workload += ", %g %% of the sequences near-copies of the query (5 %% substitutions)" % (100 * cfg["similar"])
         block = {
             "value": round(gcups, 3), "unit": "GCUPS", "steps": steps, "warmup": warmup,
@@ -357,6 +369,17 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
                           "topk_host": round(float(last["topk_ms"]), 4)},
             "setup_s": {"generate": round(t_gen, 3), "pack": round(t_pack, 3)},
         }
+        if first_search_leg:
+            # The first search of a (query, database): it plans, builds the pair tokens, and -- on a database whose
+            # relatives the f16 cells flag -- learns what the later searches' plans assume (how long the flagged list
+            # is; whether the f16 cells pay at all).  Device times of that one search beside the steady state above.
+            block["first_search"] = {"fill_ms": round(float(first_st["fill_ms"]), 4), "rescore_ms": round(float(first_st["rescore_ms"]), 4),
+                                     "device_total_ms": round(float(first_st["total_ms"]), 4), "wall_ms": round(first_wall_ms, 3),
+                                     "n_rescored": int(first_st["n_rescored"]), "cell_form": int(first_st["cell_form"]),
+                                     "gcups_device": round(cells_local / (float(first_st["total_ms"]) * 1e-3) / 1e9, 1)}
+            block["steady_state"] = {"n_rescored": int(last["n_rescored"]), "cell_form": int(last["cell_form"]),
+                                     "fill_ms": round(step_fill_ms, 4),
+                                     "rescore_ms": round(float(np.mean([st["rescore_ms"] for st in lasts])), 4)}
         if per_rank is not None:
             block["per_rank"] = per_rank
         if verify is not None:
@@ -805,26 +828,25 @@ def main():
         out["configs"] = {str(args.config): {k: v for k, v in block.items() if k not in ("cpu_baseline", "host_inclusive")}}
         emit(out)
     else:
-        # the headline first (exactly K timed steps after W warm-up steps), then the other shapes with
-        # step counts scaled to their step time so the whole run stays within minutes
+        # The headline first (exactly K timed steps after W warm-up steps): config 4's ONE 10M-sequence database,
+        # whole, on this GPU -- through the sharded path with one shard, i.e. the very workload `--gpus N` deals over
+        # N ranks, so that value(N) / (N * value(1)) compares one workload with itself.  Then the other shapes with
+        # step counts scaled to their step time so the whole run stays within minutes.
         blocks = {}
-        head = run_config(env, HEADLINE, K, W, cpu_leg=True)
-        blocks[str(HEADLINE)] = {k: v for k, v in head.items() if k != "cpu_baseline"}
+        head = run_config(env, SHARDED, K, W, sharded=True, n_override=CONFIGS[SHARDED]["n_full"], cpu_leg=True)
         out = line_from(head, env, "strong")
         if not args.only_headline:
+            blocks["3"] = run_config(env, 3, K, W)
             # (a step of config 2 is 2 ms: W such steps are over before the clocks have settled after the host-side
-            # set-up of the block, so this block -- not the headline, whose W is the caller's -- warms up for 30 steps)
+            # set-up of the block, so this block warms up for 30 steps)
             blocks["2"] = run_config(env, 2, K, max(W, 30), host_inclusive_leg=True)
             blocks["4"] = run_config(env, 4, max(2, K // 5), min(W, 2))
+            blocks["4_relatives"] = run_config(env, 7, max(2, K // 5), min(W, 2), first_search_leg=True)
             blocks["5"] = run_config(env, 5, 2, 1, legs=CONFIG_LEGS[5])
             blocks["5_stress"] = run_config(env, 6, 2, 1, legs=CONFIG_LEGS[6])
             if "host_inclusive" in blocks["2"]:
                 out["host_inclusive"] = blocks["2"]["host_inclusive"]      # quoted on config 2, as in round 1
-            if not args.no_scaling_reference:
-                # config 4 whole (10M sequences) on this one GPU, through the sharded path with one shard:
-                # the N = 1 point of the strong-scaling curve the N > 1 runs continue
-                out["scaling_reference"] = run_config(env, SHARDED, 2, 1, sharded=True,
-                                                      n_override=CONFIGS[SHARDED]["n_full"])
+        blocks["4_whole"] = {k: v for k, v in head.items() if k != "cpu_baseline"}
         out["configs"] = blocks
         emit(out)
     env.close()

@@ -182,6 +182,10 @@ int swg_db_pack(const int8_t *flat, const uint64_t *offsets, size_t n,
  * sorted order, in that order, the result equals swg_db_pack(whole, rank, count). */
 int swg_db_pack_shard(const int8_t *flat, const uint64_t *offsets, size_t n_local,
                       const uint32_t *global_index, size_t n_total, swg_db **out);
+/* All shard_count shards of one database at once: out[r] == swg_db_pack(flat, offsets, n, r, shard_count), from ONE
+ * global sort and with the shards built side by side (what swg_group_load uses: one process driving several GPUs
+ * should not sort a 10M-sequence database once per device).  On error no shard is returned. */
+int swg_db_pack_shards(const int8_t *flat, const uint64_t *offsets, size_t n, int shard_count, swg_db **out);
 int swg_db_upload(swg_ctx *ctx, swg_db *db); /* H2D; db becomes resident on ctx's GPU */
 /* Packed-database file (host-only): the sorted, re-coded image of swg_db_pack,
  * so a large database is ingested once; swg_db_load validates the structure it reads. */

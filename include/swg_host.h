@@ -82,6 +82,13 @@ void swg_synth_query(uint64_t seed, size_t lq, int8_t *out);
 int swg_synth_db_similar(uint64_t seed, size_t n, double median, double sigma_ln, uint32_t min_len,
                          uint32_t max_len, const int8_t *query, size_t lq, double fraction,
                          double subst, int8_t **flat_out, uint64_t **offsets_out, size_t *n_planted);
+/* A family of relatives instead of near-copies: as swg_synth_db_similar, but every planted sequence draws
+ * its own substitution rate from [subst_lo, subst_hi] (identity 1 - rate: 0.3 .. 0.7 gives scores between
+ * the f16 cells' ceiling and int16's for a 3000-aa query).  subst_hi == subst_lo is swg_synth_db_similar. */
+int swg_synth_db_family(uint64_t seed, size_t n, double median, double sigma_ln, uint32_t min_len,
+                        uint32_t max_len, const int8_t *query, size_t lq, double fraction,
+                        double subst_lo, double subst_hi, int8_t **flat_out, uint64_t **offsets_out,
+                        size_t *n_planted);
 /* One shard of the same database without generating the rest: the sequences of the global bins
  * (128 consecutive sorted ranks) b with b % shard_count == shard_rank -- exactly the bins
  * swg_db_pack(..., shard_rank, shard_count) keeps of the whole database.  offsets_out[n_local+1]

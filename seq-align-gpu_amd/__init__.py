@@ -32,7 +32,7 @@ SWG_ERR_STATE, SWG_ERR_RESIDUE, SWG_ERR_IO, SWG_ERR_NODEVICE = -4, -5, -6, -7
 # every symbol declared in include/swg.h and include/swg_host.h
 ABI_SYMBOLS = [
     "swg_create", "swg_destroy", "swg_last_error", "swg_global_error", "swg_abi_version",
-    "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_pack_shard", "swg_db_upload",
+    "swg_set_option", "swg_set_scoring", "swg_set_query", "swg_db_pack", "swg_db_pack_shard", "swg_db_pack_shards", "swg_db_upload",
     "swg_db_free", "swg_db_save", "swg_db_load", "swg_db_count", "swg_db_total_count", "swg_db_residues",
     "swg_db_packed_bytes", "swg_db_order", "swg_search", "swg_search_begin", "swg_search_end", "swg_search_multi",
     "swg_fill_batches16", "swg_align_hits", "swg_align_ops_bound", "swg_hit_key",
@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "swg_group_align_hits", "swg_group_align_ops_bound",
     "swg_letter_index", "swg_index_letter", "swg_scoring_init", "swg_scoring_add",
     "swg_scoring_load_matrix", "swg_query_sanitize", "swg_seqs_read", "swg_seqs_free",
-    "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar", "swg_synth_db_shard",
+    "swg_seqs_to_indices", "swg_synth_db", "swg_synth_query", "swg_synth_db_similar", "swg_synth_db_family", "swg_synth_db_shard",
     "swg_synth_free", "swg_host_threads",
 ]
 
@@ -124,6 +124,7 @@ _sig("swg_set_scoring", C.c_int, [_vp, _vp, C.c_int, C.c_int])
 _sig("swg_set_query", C.c_int, [_vp, _vp, C.c_size_t])
 _sig("swg_db_pack", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_vp)])
 _sig("swg_db_pack_shard", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(_vp)])
+_sig("swg_db_pack_shards", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(_vp)])
 _sig("swg_db_upload", C.c_int, [_vp, _vp])
 _sig("swg_db_free", None, [_vp])
 _sig("swg_db_save", C.c_int, [_vp, C.c_char_p])
@@ -169,12 +170,17 @@ _sig("swg_synth_query", None, [C.c_uint64, C.c_size_t, _vp])
 _sig("swg_synth_db_similar", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_double, C.c_uint32,
                                        C.c_uint32, _vp, C.c_size_t, C.c_double, C.c_double,
                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)])
+_sig("swg_synth_db_family", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_double, C.c_uint32,
+                                      C.c_uint32, _vp, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                      C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)])
 _sig("swg_synth_db_shard", C.c_int, [C.c_uint64, C.c_size_t, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
                                      _vp, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
                                      C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)])
 _sig("swg_synth_free", None, [_vp])
 # test hook, declared in csrc/swg_host_internal.h (not part of the public ABI)
+_sig("swg_debug_fail_alloc", None, [C.c_int])
+_sig("swg_debug_sort_count", C.c_ulong, [])
 _sig("swg_debug_plan", C.c_int, [_vp, C.c_size_t, C.c_int, _vp])
 _sig("swg_debug_split", C.c_int, [_vp, C.c_size_t, C.c_uint64, _vp])
 _sig("swg_debug_pair_tokens", C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)])
@@ -275,8 +281,10 @@ _OWNERS = {}
 
 
 def synth_db(seed, n, median=290.0, sigma_ln=0.75, min_len=20, max_len=5000, query=None,
-             fraction=0.0, subst=0.05):
-    """Synthetic database -> (flat int8, offsets uint64[n+1][, n_planted])."""
+             fraction=0.0, subst=0.05, subst_hi=None):
+    """Synthetic database -> (flat int8, offsets uint64[n+1][, n_planted]).
+    subst_hi: the planted sequences are a family of relatives, each with its own substitution rate
+    from [subst, subst_hi]."""
     flat, off = _vp(), _vp()
     if query is None or fraction <= 0.0:
         _check(lib.swg_synth_db(seed, n, median, sigma_ln, min_len, max_len, C.byref(flat), C.byref(off)))
@@ -284,8 +292,12 @@ def synth_db(seed, n, median=290.0, sigma_ln=0.75, min_len=20, max_len=5000, que
     else:
         q, qp = _i8(query)
         npl = C.c_size_t(0)
-        _check(lib.swg_synth_db_similar(seed, n, median, sigma_ln, min_len, max_len, qp, len(q),
-                                        fraction, subst, C.byref(flat), C.byref(off), C.byref(npl)))
+        if subst_hi is not None:
+            _check(lib.swg_synth_db_family(seed, n, median, sigma_ln, min_len, max_len, qp, len(q),
+                                           fraction, subst, subst_hi, C.byref(flat), C.byref(off), C.byref(npl)))
+        else:
+            _check(lib.swg_synth_db_similar(seed, n, median, sigma_ln, min_len, max_len, qp, len(q),
+                                            fraction, subst, C.byref(flat), C.byref(off), C.byref(npl)))
         planted = npl.value
     offsets = _take(off, (n + 1) * 8, np.uint64)
     residues = _take(flat, int(offsets[n]), np.int8)
@@ -366,6 +378,20 @@ class Database:
             _check(lib.swg_db_pack(fp, self._off.ctypes.data_as(_vp), n, shard_rank, shard_count, C.byref(h)))
         self.handle = h
         self._flat = None  # the library copied what it needs
+
+    @classmethod
+    def pack_shards(cls, flat, offsets, shard_count):
+        """All shards of one database from ONE global sort (what swg_group_load uses) -> [Database] * shard_count."""
+        f, fp = _i8(flat)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        hs = (_vp * shard_count)()
+        _check(lib.swg_db_pack_shards(fp, off.ctypes.data_as(_vp), off.size - 1, shard_count, hs))
+        out = []
+        for h in hs:
+            d = cls.__new__(cls)
+            d.handle = _vp(h)
+            out.append(d)
+        return out
 
     count = property(lambda self: lib.swg_db_count(self.handle))
     total_count = property(lambda self: lib.swg_db_total_count(self.handle))

@@ -8,6 +8,7 @@
 #include "swg_host_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +21,9 @@
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
+// (query, scoring) epochs are unique in the process, not per context: a database keeps hints keyed by the epoch
+// (f16_veto_epoch), and two contexts that both counted from 1 would hand each other's hints on
+static std::atomic<uint64_t> g_epoch{1};
 
 int swg_set_global_error(int code, const char *fmt, ...)
 {
@@ -69,6 +73,35 @@ static hipError_t spin_sync(swg_ctx *ctx, hipStream_t s)
     }
 }
 
+// No C++ exception crosses the ABI (include/swg.h:9-12): the bodies below touch std containers -- the plan cache of a
+// database (std::map), the fall-back key vector of swg_search_end (up to n_local keys) -- so every hot entry point
+// runs its body inside this guard; an allocation failure or any other std::exception becomes SWG_ERR_NOMEM with
+// the text in swg_last_error.  (The reference asserts / exits instead: src/alignment.c:63-66.)
+template <class F> static int ctx_guarded(swg_ctx *ctx, const char *what, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "%s: %s", what, e.what());
+    }
+}
+
+// Test hook (csrc/swg_host_internal.h, not part of the public ABI): the next time the named site is reached it
+// throws std::bad_alloc as a failed allocation there would.  Sites: 1 = body of swg_search_begin, 2 = body of
+// swg_search_end, 3 = the fall-back key vector of swg_search_end (reached only when the device top-K could not be
+// used).  One shot: the hook clears itself when it fires.
+static int g_fail_alloc_site = 0;
+extern "C" void swg_debug_fail_alloc(int site) { g_fail_alloc_site = site; }
+static inline void fail_alloc_here(int site)
+{
+    if (g_fail_alloc_site == site) {
+        g_fail_alloc_site = 0;
+        throw std::bad_alloc();
+    }
+}
+
 extern "C" const char *swg_last_error(const swg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 extern "C" const char *swg_global_error(void) { return g_err.c_str(); }
 extern "C" int swg_abi_version(void) { return SWG_ABI_VERSION; }
@@ -92,6 +125,7 @@ extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
     swg_ctx *ctx = new (std::nothrow) swg_ctx();
     if (!ctx) return swg_set_global_error(SWG_ERR_NOMEM, "swg_create: out of memory");
     ctx->device = dev;
+    ctx->epoch = g_epoch.fetch_add(1) + 1;
     memset(ctx->sub, 0, sizeof ctx->sub);
     int rc = [&]() -> int {
         HIP_TRY(ctx, hipSetDevice(dev));
@@ -242,7 +276,7 @@ extern "C" int swg_set_scoring(swg_ctx *ctx, const int8_t sub[32][32], int gap_o
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sub, ctx->sub, 32 * 32, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_scoring = true;
-    ctx->epoch++;
+    ctx->epoch = g_epoch.fetch_add(1) + 1;
     return SWG_OK;
 }
 
@@ -285,7 +319,7 @@ extern "C" int swg_set_query(swg_ctx *ctx, const int8_t *idx, size_t lq)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_query, ctx->h_query_stage[b], lq, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_query_stage[b], ctx->stream));
     }
-    ctx->epoch++;
+    ctx->epoch = g_epoch.fetch_add(1) + 1;
     return SWG_OK;
 }
 
@@ -2144,6 +2178,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         if (cand_ok) {
             keys.assign(h_cand, h_cand + h_counters[3]);
         } else {
+            fail_alloc_here(3);
             keys.reserve(db->n_local);
             for (size_t i = 0; i < n_slots; ++i) {
                 const uint32_t oi = db->order[i];
@@ -2162,32 +2197,40 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
 
 extern "C" int swg_search_begin(swg_ctx *ctx, const swg_db *db, int want_scores, size_t k, int *ticket)
 {
-    if (!ctx || !db || !ticket) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_begin: NULL argument");
-    int slot = -1;
-    for (int i = 0; i < SWG_MAX_INFLIGHT; ++i) {
-        const int c = (ctx->next_slot + i) % SWG_MAX_INFLIGHT;
-        if (!ctx->slots[c].busy) {
-            slot = c;
-            break;
+    return ctx_guarded(ctx, "swg_search_begin", [&]() -> int {
+        fail_alloc_here(1);
+        if (!ctx || !db || !ticket) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_begin: NULL argument");
+        int slot = -1;
+        for (int i = 0; i < SWG_MAX_INFLIGHT; ++i) {
+            const int c = (ctx->next_slot + i) % SWG_MAX_INFLIGHT;
+            if (!ctx->slots[c].busy) {
+                slot = c;
+                break;
+            }
         }
-    }
-    if (slot < 0)
-        return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_begin: %d searches already in flight", SWG_MAX_INFLIGHT);
-    const int rc = search_begin(ctx, db, want_scores != 0, k, &ctx->slots[slot]);
-    if (rc != SWG_OK) return rc;
-    ctx->slots[slot].busy = true;
-    ctx->next_slot = (slot + 1) % SWG_MAX_INFLIGHT;
-    *ticket = slot;
-    return SWG_OK;
+        if (slot < 0)
+            return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_begin: %d searches already in flight", SWG_MAX_INFLIGHT);
+        const int rc = search_begin(ctx, db, want_scores != 0, k, &ctx->slots[slot]);
+        if (rc != SWG_OK) return rc;
+        ctx->slots[slot].busy = true;
+        ctx->next_slot = (slot + 1) % SWG_MAX_INFLIGHT;
+        *ticket = slot;
+        return SWG_OK;
+    });
 }
 
 extern "C" int swg_search_end(swg_ctx *ctx, int ticket, int32_t *scores_out, swg_hit *topk_out, size_t *n_hits,
                               swg_stats *stats)
 {
-    if (!ctx || ticket < 0 || ticket >= SWG_MAX_INFLIGHT || !ctx->slots[ticket].busy)
-        return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_end: no search in flight under that ticket");
-    const int rc = search_end(ctx, &ctx->slots[ticket], scores_out, topk_out, n_hits, stats);
-    ctx->slots[ticket].busy = false;
+    bool valid = false; // the ticket named a search in flight: it is spent whatever happens next (a failed read-out is not retried)
+    const int rc = ctx_guarded(ctx, "swg_search_end", [&]() -> int {
+        fail_alloc_here(2);
+        if (!ctx || ticket < 0 || ticket >= SWG_MAX_INFLIGHT || !ctx->slots[ticket].busy)
+            return swg_set_ctx_error(ctx, SWG_ERR_ARG, "swg_search_end: no search in flight under that ticket");
+        valid = true;
+        return search_end(ctx, &ctx->slots[ticket], scores_out, topk_out, n_hits, stats);
+    });
+    if (valid) ctx->slots[ticket].busy = false;
     return rc;
 }
 
@@ -2222,6 +2265,11 @@ struct MultiBufs {
     uint32_t *d_cnt = nullptr;
     uint32_t *d_hist = nullptr, *d_meta = nullptr; // device top-K of the batch (no score array asked for)
     uint64_t *d_cand = nullptr;
+    // How many rows each per-query buffer holds, written where the buffer is allocated and checked against what a
+    // launch will index before every launch (multi_rows_ok): with two queries per lane the grid's row y stands for
+    // queries 2y and 2y+1, so a batch of odd size indexes ONE ROW MORE than it has queries.  Round 3 sized these
+    // buffers by the queries and a wavefront of the last pair ran off the end ("the fault of round 3").
+    size_t rows_scores = 0, rows_order = 0, rows_prof[2] = {0, 0}, rows_cnt = 0, rows_topk = 0;
     ~MultiBufs()
     {
         (void)hipFree(d_hist);
@@ -2237,6 +2285,27 @@ struct MultiBufs {
     }
 };
 } // namespace
+
+// Every per-query buffer of a batch launch against the rows the launch indexes: Qb queries, Qrows grid rows (query
+// pairs when two queries share a lane: the kernels then address score rows 2y and 2y+1 for y < Qrows, i.e. Qb + 1
+// rows for an odd batch).  A mismatch is a bug of this file; it is reported, not launched.
+static int multi_rows_ok(swg_ctx *ctx, const MultiBufs &B, bool qq, size_t Qb, size_t Qrows, int n_classes, bool dev_topk)
+{
+    const size_t score_rows = qq ? 2 * Qrows : Qb; // rows of d_scores a launch may write
+    const size_t order_rows = qq ? 2 * Qrows : 0;  // entries of d_order the profile builder may read
+    struct { const char *name; size_t have, need; } chk[] = {
+        {"d_scores", B.rows_scores, score_rows},       {"d_order", B.rows_order, order_rows},
+        {"d_prof[0]", B.rows_prof[0], Qrows},          {"d_prof[1]", n_classes == 2 ? B.rows_prof[1] : Qrows, Qrows},
+        {"d_cnt", B.rows_cnt, Qrows},                  {"d_hist/d_meta/d_cand", dev_topk ? B.rows_topk : Qb, Qb},
+    };
+    if ((qq && Qrows != (Qb + 1) / 2) || (!qq && Qrows != Qb))
+        return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_multi: %zu grid rows for %zu queries (qq %d)", Qrows, Qb, (int)qq);
+    for (const auto &c : chk)
+        if (c.have < c.need)
+            return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search_multi: %s holds %zu rows, the launch indexes %zu (batch of %zu, qq %d)",
+                                     c.name, c.have, c.need, Qb, (int)qq);
+    return SWG_OK;
+}
 
 static void multi_deliver(const swg_db *db, const int32_t *h_scores, size_t n_slots, int32_t *scores_out, swg_hit *topk_out,
                           size_t k, size_t *n_hits)
@@ -2451,31 +2520,46 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
             std::stable_sort(order.begin(), order.end(),
                              [&](uint32_t a, uint32_t b) { return qoff32[a + 1] - qoff32[a] > qoff32[b + 1] - qoff32[b]; });
         if (q0 == 0) {
+            // rows are counted in QUERIES for scores / order / top-K, in grid rows (query pairs with qq) for the
+            // profiles and the queues; a qq batch gets an even number of query rows, so that the absent partner of an
+            // odd batch's last query has a row of its own everywhere (nothing reads it back)
+            const size_t qm = std::min(Qb_max, n_queries);
+            const size_t q_rows = qq ? (qm + 1) / 2 * 2 : qm, g_rows = qq ? (qm + 1) / 2 : qm;
             const size_t cnt_dwords = Qb_max * 2 * cnt_class + 2 * SWG_DYN_SIMD_SLOTS;
             HIP_TRY(ctx, hipMalloc(&B.d_cnt, cnt_dwords * 4));
-            HIP_TRY(ctx, hipMalloc(&B.d_scores, std::min(Qb_max, n_queries) * n_slots * 4));
+            B.rows_cnt = Qb_max;
+            HIP_TRY(ctx, hipMalloc(&B.d_scores, q_rows * n_slots * 4));
+            B.rows_scores = q_rows;
             HIP_TRY(ctx, hipMalloc(&B.d_qoff, (Qb_max + 1) * 4));
-            HIP_TRY(ctx, hipMalloc(&B.d_order, Qb_max * 4));
+            HIP_TRY(ctx, hipMalloc(&B.d_order, (Qb_max + 1) * 4));
+            B.rows_order = Qb_max + 1;
             if (dev_topk) {
-                const size_t qm = std::min(Qb_max, n_queries);
                 HIP_TRY(ctx, hipMalloc(&B.d_hist, qm * 4096 * 4));
                 HIP_TRY(ctx, hipMalloc(&B.d_meta, qm * 16));
                 HIP_TRY(ctx, hipMalloc(&B.d_cand, qm * (size_t)SWG_TOPK_MULTI_CAP * 8));
+                B.rows_topk = qm;
             }
             for (int c = 0; c < wk.n_classes; ++c) {
                 // (qq: one profile of 128 bytes per column per query PAIR, and an odd batch's last pair is a whole pair)
-                const size_t rows_max = qq ? (std::min(Qb_max, n_queries) + 1) / 2 : std::min(Qb_max, n_queries);
                 const size_t per_row = (size_t)wk.plan[c].G * (qq ? (size_t)swg_q32_padded_cols(wk.plan[c].K) * 128 : (size_t)swg_diag_padded_cols(wk.plan[c].K) * 64);
-                HIP_TRY(ctx, hipMalloc(&B.d_prof[c], rows_max * per_row));
+                HIP_TRY(ctx, hipMalloc(&B.d_prof[c], g_rows * per_row));
+                B.rows_prof[c] = g_rows;
             }
+        }
+        {
+            // the fence: what this chunk's launches will index, against what the buffers hold
+            const int rf = multi_rows_ok(ctx, B, qq, Qb, Qrows, wk.n_classes, dev_topk);
+            if (rf != SWG_OK) return rf;
         }
         (void)hipFree(B.d_q);
         B.d_q = nullptr;
         HIP_TRY(ctx, hipMalloc(&B.d_q, std::max<uint64_t>(4, qbytes)));
         HIP_TRY(ctx, hipMemcpyAsync(B.d_q, queries + q_offsets[q0], qbytes, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(B.d_qoff, qoff32.data(), (Qb + 1) * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(B.d_order, order.data(), Qb * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemsetAsync(B.d_scores, 0, Qb * n_slots * 4, s));
+        order.push_back(order.back()); // (qq, odd batch: the last pair's absent partner is its query once more)
+        HIP_TRY(ctx, hipMemcpyAsync(B.d_order, order.data(), (Qb + 1) * 4, hipMemcpyHostToDevice, s));
+        order.pop_back();
+        HIP_TRY(ctx, hipMemsetAsync(B.d_scores, 0, (qq ? 2 * Qrows : Qb) * n_slots * 4, s));
         HIP_TRY(ctx, hipMemsetAsync(B.d_cnt, 0, (Qb_max * 2 * cnt_class + 2 * SWG_DYN_SIMD_SLOTS) * 4, s));
         for (int c = 0; c < wk.n_classes; ++c) {
             const SwgDiagPlan &pl = wk.plan[c];
@@ -2675,40 +2759,56 @@ static int fill_batches16_device(swg_ctx *ctx, const swg_batch16 *batches, size_
     const size_t n_slots = (2 * n_pairs + SWG_BIN - 1) / SWG_BIN * SWG_BIN;
     // ---- buffers: grown, never shrunk ---------------------------------------------------------
     if (!C.db || n_slots > C.slots_cap || n_pairs > C.pairs_cap || total_blocks > C.blocks_cap || stage_bytes > C.stage_cap) {
-        if (C.db) swg_db_free(C.db);
-        C.db = nullptr;
-        (void)hipHostFree(C.h_stage);
-        (void)hipHostFree(C.h_meta);
-        (void)hipFree(C.d_stage);
-        (void)hipFree(C.d_pair_src);
-        (void)hipFree(C.d_pair_len);
-        C.h_stage = C.h_meta = nullptr;
-        C.d_stage = nullptr;
-        C.d_pair_src = nullptr;
-        C.d_pair_len = nullptr;
+        // The new capacities live in locals until EVERY allocation has succeeded: a failure half way leaves the cache
+        // empty (capacities 0, no database), so the next call grows again instead of writing through NULL buffers.
+        auto release = [&C]() {
+            if (C.db) swg_db_free(C.db);
+            C.db = nullptr;
+            (void)hipHostFree(C.h_stage);
+            (void)hipHostFree(C.h_meta);
+            (void)hipFree(C.d_stage);
+            (void)hipFree(C.d_pair_src);
+            (void)hipFree(C.d_pair_len);
+            C.h_stage = C.h_meta = nullptr;
+            C.d_stage = nullptr;
+            C.d_pair_src = nullptr;
+            C.d_pair_len = nullptr;
+        };
         auto grow = [](uint64_t need, uint64_t have) { return std::max<uint64_t>(need + need / 4 + 64, have); };
-        C.slots_cap = (size_t)((grow(n_slots, C.slots_cap) + SWG_BIN - 1) / SWG_BIN * SWG_BIN);
-        C.pairs_cap = (size_t)grow(n_pairs, C.pairs_cap);
-        C.blocks_cap = grow(total_blocks, C.blocks_cap);
-        C.stage_cap = (size_t)grow(stage_bytes, C.stage_cap);
-        swg_db *db = new (std::nothrow) swg_db();
-        if (!db) return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of memory");
-        C.db = db;
-        db->tokens_only = true;
-        db->device = ctx->device;
-        db->n_bins = (uint32_t)(C.slots_cap / SWG_BIN); // (sizes the per-search output buffers)
-        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&C.h_stage), C.stage_cap, hipHostMallocDefault));
-        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&C.h_meta), C.pairs_cap * 16 + 8 + C.slots_cap * 8, hipHostMallocDefault));
-        HIP_TRY(ctx, hipMalloc(&C.d_stage, C.stage_cap));
-        HIP_TRY(ctx, hipMalloc(&C.d_pair_src, C.pairs_cap * 8));
-        HIP_TRY(ctx, hipMalloc(&C.d_pair_len, C.pairs_cap * 4));
-        HIP_TRY(ctx, hipMalloc(&db->d_codes, 16)); // (marks the database resident; there are no residue bytes by rank)
-        HIP_TRY(ctx, hipMalloc(&db->d_lens, C.slots_cap * 4));
-        HIP_TRY(ctx, hipMalloc(&db->d_order, C.slots_cap * 4));
-        HIP_TRY(ctx, hipMalloc(&db->ptok.d_tok, (size_t)(C.blocks_cap + 1) * 16));
-        HIP_TRY(ctx, hipMalloc(&db->ptok.d_pair_off, (C.pairs_cap + 1) * 4));
-        int rb = select_bufs(ctx, db, 0);
-        if (rb != SWG_OK) return rb;
+        const size_t slots_cap = (size_t)((grow(n_slots, C.slots_cap) + SWG_BIN - 1) / SWG_BIN * SWG_BIN);
+        const size_t pairs_cap = (size_t)grow(n_pairs, C.pairs_cap);
+        const uint64_t blocks_cap = grow(total_blocks, C.blocks_cap);
+        const size_t stage_cap = (size_t)grow(stage_bytes, C.stage_cap);
+        release();
+        C.slots_cap = C.pairs_cap = C.stage_cap = 0;
+        C.blocks_cap = 0;
+        const int ra = [&]() -> int {
+            swg_db *db = new (std::nothrow) swg_db();
+            if (!db) return swg_set_ctx_error(ctx, SWG_ERR_NOMEM, "swg_fill_batches16: out of memory");
+            C.db = db;
+            db->tokens_only = true;
+            db->device = ctx->device;
+            db->n_bins = (uint32_t)(slots_cap / SWG_BIN); // (sizes the per-search output buffers)
+            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&C.h_stage), stage_cap, hipHostMallocDefault));
+            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&C.h_meta), pairs_cap * 16 + 8 + slots_cap * 8, hipHostMallocDefault));
+            HIP_TRY(ctx, hipMalloc(&C.d_stage, stage_cap));
+            HIP_TRY(ctx, hipMalloc(&C.d_pair_src, pairs_cap * 8));
+            HIP_TRY(ctx, hipMalloc(&C.d_pair_len, pairs_cap * 4));
+            HIP_TRY(ctx, hipMalloc(&db->d_codes, 16)); // (marks the database resident; there are no residue bytes by rank)
+            HIP_TRY(ctx, hipMalloc(&db->d_lens, slots_cap * 4));
+            HIP_TRY(ctx, hipMalloc(&db->d_order, slots_cap * 4));
+            HIP_TRY(ctx, hipMalloc(&db->ptok.d_tok, (size_t)(blocks_cap + 1) * 16));
+            HIP_TRY(ctx, hipMalloc(&db->ptok.d_pair_off, (pairs_cap + 1) * 4));
+            return select_bufs(ctx, db, 0);
+        }();
+        if (ra != SWG_OK) {
+            release();
+            return ra;
+        }
+        C.slots_cap = slots_cap;
+        C.pairs_cap = pairs_cap;
+        C.blocks_cap = blocks_cap;
+        C.stage_cap = stage_cap;
     }
     swg_db *db = C.db;
     // ---- this call's database: ranks 2p, 2p+1 = lanes 2i, 2i+1 of a batch --------------------------------
@@ -2754,7 +2854,10 @@ static int fill_batches16_device(swg_ctx *ctx, const swg_batch16 *batches, size_
     db->residues = residues;
     db->max_nblk = (uint32_t)((longest + 3) / 4);
     db->rows_padded = 0;
+    // one macro-batch has nothing to tell the next: plans and hints start afresh with the cache's database
     db->tuned.clear();
+    db->sat_hint = -1;
+    db->f16_veto_epoch = 0;
     SwgPairTokens &T = db->ptok;
     T.tried = T.ok = true;
     T.total_blocks = total_blocks;
@@ -2772,11 +2875,7 @@ static int fill_batches16_device(swg_ctx *ctx, const swg_batch16 *batches, size_
             uint64_t bytes = 0;
             while (k1 < n_batches && bytes < (4u << 20)) bytes += (uint64_t)batches[bo[k1++]].max_len * 16u;
             const long long lo = (long long)k0, hi = (long long)k1;
-#pragma omp parallel for schedule(dynamic, 16) num_threads(swg_host_threads())
-            for (long long k = lo; k < hi; ++k) {
-                const swg_batch16 &bt = batches[bo[k]];
-                memcpy(C.h_stage + stage_off[bo[k]], bt.db_idx_t, (size_t)bt.max_len * 16u);
-            }
+            swg_stage_batches16(batches, bo.data(), stage_off.data(), (size_t)lo, (size_t)hi, C.h_stage); // all cores (swg_pack.cpp)
             const uint64_t from = stage_off[bo[k0]];
             HIP_TRY(ctx, hipMemcpyAsync(C.d_stage + from, C.h_stage + from, bytes, hipMemcpyHostToDevice, s));
             k0 = k1;

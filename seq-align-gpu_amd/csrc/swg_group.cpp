@@ -165,10 +165,24 @@ extern "C" int swg_group_load(swg_group *g, const int8_t *flat, const uint64_t *
     for (int i = 0; i < g->n; ++i) {
         swg_db_free(g->db[i]);
         g->db[i] = nullptr;
-        int rc = swg_db_pack(flat, offsets, n, i, g->n, &g->db[i]);
+    }
+    // ONE global sort for all the devices (round 3 packed -- i.e. sorted -- the whole database once per device, one
+    // after another); the shards are cut from it side by side, one host thread per device, and each thread uploads
+    // its shard as soon as it is built, so a device's transfer runs beside the other shards' re-coding.
+    std::vector<std::string> up_err((size_t)g->n);
+    try {
+        const int rc = swg_pack_shards(flat, offsets, n, g->n, g->db.data(), [&](int r, swg_db *db) -> int {
+            const int ru = swg_db_upload(g->ctx[r], db);
+            if (ru != SWG_OK) swg_set_global_error(ru, "upload to device %d: %s", g->devices[r], swg_last_error(g->ctx[r]));
+            return ru;
+        });
         if (rc != SWG_OK) return gerr(g, rc, swg_global_error());
-        rc = swg_db_upload(g->ctx[i], g->db[i]);
-        if (rc != SWG_OK) return gerr(g, rc, swg_last_error(g->ctx[i]));
+    } catch (const std::exception &e) {
+        for (int i = 0; i < g->n; ++i) {
+            swg_db_free(g->db[i]);
+            g->db[i] = nullptr;
+        }
+        return gerr(g, SWG_ERR_NOMEM, std::string("swg_group_load: ") + e.what());
     }
     g->n_total = n;
     return SWG_OK;

@@ -4,6 +4,7 @@
 #include "../../include/swg.h"
 #include "swg_internal.h"
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <new>
@@ -258,6 +259,8 @@ int swg_set_ctx_error(swg_ctx *ctx, int code, const char *fmt, ...)
     __attribute__((format(printf, 3, 4)));
 void swg_db_release_device(swg_db *db);
 // test hook: the pair-token image as the device built it, or as the host restatement builds it
+// test hook: the next visit of the named site throws std::bad_alloc (swg_api.cpp); 0 disarms
+extern "C" void swg_debug_fail_alloc(int site);
 extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *out);
 extern "C" int swg_debug_split(swg_db *db, size_t lq, uint64_t qbound, uint64_t *out);
 // decisions swg_search_begin makes on top of the planner's geometry (host only: swg_diag_host.cpp)
@@ -284,6 +287,12 @@ int swg_build_pair_tokens(const swg_db *db, std::unique_ptr<uint32_t[]> *tok, si
                           std::vector<uint32_t> *pair_off);
 void swg_build_diag_layout(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint32_t n_streams,
                            uint32_t streams_per_wg, SwgDiagLayout *out);
+// every shard of one database from one global sort (swg_pack.cpp); ready(r, shard) runs on the thread that built shard r
+int swg_pack_shards(const int8_t *flat, const uint64_t *offsets, size_t n, int shard_count, swg_db **out,
+                    const std::function<int(int, swg_db *)> &ready);
+extern "C" unsigned long swg_debug_sort_count(void); // test hook: global sorts run by this process so far
+void swg_stage_batches16(const swg_batch16 *batches, const uint32_t *order, const uint64_t *stage_off, size_t lo, size_t hi,
+                         uint8_t *stage);
 void swg_untranspose_batches16(const swg_batch16 *batches, size_t n_batches, const size_t *first_rec,
                                const uint64_t *rec_off, int8_t *flat);
 uint64_t swg_db_pair_count(const swg_db *db);

@@ -12,11 +12,15 @@
 #include "../../include/swg_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 // Bins, slot tables and offsets from the lengths by sorted slot (db->lens, db->order filled in).
@@ -47,42 +51,25 @@ static void derive_tables(swg_db *db)
     db->max_nblk = nb ? *std::max_element(db->bin_nblk.begin(), db->bin_nblk.end()) : 0;
 }
 
-// global_index: NULL (the sequences given ARE the database, index = position), or the original
-// index of each sequence given (a shard that was cut elsewhere: swg_db_pack_shard); n_total: size
-// of the whole database the indices refer to.
-static int pack_impl(const int8_t *flat, const uint64_t *offsets, size_t n, const uint32_t *global_index,
-                     size_t n_total, int shard_rank, int shard_count, swg_db **out)
-{
-    if (!out) return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: out is NULL");
-    *out = nullptr;
-    if (!offsets && n > 0) return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: NULL input");
-    if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count)
-        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: bad shard %d/%d", shard_rank,
-                                    shard_count);
-    if (n >= 0xFFFFFFF0ull)
-        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: too many sequences");
-    swg_db *db = new (std::nothrow) swg_db();
-    if (!db) return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
-    std::unique_ptr<swg_db> holder(db); // freed on every error path, exceptions included
-    db->n_total = n_total;
-    if (n == 0) { // nothing to read: offsets may be NULL
-        derive_tables(db);
-        *out = holder.release();
-        return SWG_OK;
-    }
-    if (!flat && offsets[n] > offsets[0])
-        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: NULL input");
+// Step 1 of packing, once per database whatever the number of shards: validation (the reference exits in
+// letters_to_index on anything outside A-Z/a-z/'*'; here an index outside 1..31 is an error code) and the global
+// order -- a stable counting sort by length, descending.
+static std::atomic<unsigned long> g_sorts{0}; // how many global sorts this process has run (swg_debug_sort_count)
+extern "C" unsigned long swg_debug_sort_count(void) { return g_sorts.load(); }
 
-    // lengths + validation (the reference exits in letters_to_index on anything
-    // outside A-Z/a-z/'*'; here an index outside 1..31 is an error code)
+static int sort_database(const char *what, const int8_t *flat, const uint64_t *offsets, size_t n, std::vector<uint32_t> *sorted)
+{
+    if (!offsets && n > 0) return swg_set_global_error(SWG_ERR_ARG, "%s: NULL input", what);
+    if (n >= 0xFFFFFFF0ull) return swg_set_global_error(SWG_ERR_ARG, "%s: too many sequences", what);
+    sorted->clear();
+    if (n == 0) return SWG_OK; // nothing to read: offsets may be NULL
+    if (!flat && offsets[n] > offsets[0]) return swg_set_global_error(SWG_ERR_ARG, "%s: NULL input", what);
     uint64_t max_len = 0;
     for (size_t i = 0; i < n; ++i) {
-        if (offsets[i + 1] < offsets[i])
-            return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: offsets not monotone at %zu", i);
+        if (offsets[i + 1] < offsets[i]) return swg_set_global_error(SWG_ERR_ARG, "%s: offsets not monotone at %zu", what, i);
         max_len = std::max<uint64_t>(max_len, offsets[i + 1] - offsets[i]);
     }
-    if (max_len > 0x3FFFFFFFull)
-        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: sequence too long");
+    if (max_len > 0x3FFFFFFFull) return swg_set_global_error(SWG_ERR_ARG, "%s: sequence too long", what);
     const uint64_t total = offsets[n] - offsets[0];
     {
         int bad = 0;
@@ -91,20 +78,33 @@ static int pack_impl(const int8_t *flat, const uint64_t *offsets, size_t n, cons
             const int v = flat[i];
             bad |= (v < 1 || v > 31);
         }
-        if (bad)
-            return swg_set_global_error(SWG_ERR_RESIDUE,
-                                        "swg_db_pack: residue index outside 1..31 in database");
+        if (bad) return swg_set_global_error(SWG_ERR_RESIDUE, "%s: residue index outside 1..31 in database", what);
     }
+    sorted->resize(n);
+    std::vector<uint64_t> cnt(max_len + 2, 0);
+    for (size_t i = 0; i < n; ++i) cnt[max_len - (offsets[i + 1] - offsets[i]) + 1]++;
+    for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
+    for (size_t i = 0; i < n; ++i) (*sorted)[cnt[max_len - (offsets[i + 1] - offsets[i])]++] = (uint32_t)i;
+    g_sorts.fetch_add(1);
+    return SWG_OK;
+}
 
-    // stable counting sort by length, descending
-    std::vector<uint32_t> sorted(n);
-    {
-        std::vector<uint64_t> cnt(max_len + 2, 0);
-        for (size_t i = 0; i < n; ++i) cnt[max_len - (offsets[i + 1] - offsets[i]) + 1]++;
-        for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
-        for (size_t i = 0; i < n; ++i) sorted[cnt[max_len - (offsets[i + 1] - offsets[i])]++] = (uint32_t)i;
+// Step 2, once per shard: the bins b % shard_count == shard_rank of the global order, re-coded.
+// global_index: NULL (the sequences given ARE the database, index = position), or the original
+// index of each sequence given (a shard that was cut elsewhere: swg_db_pack_shard); n_total: size
+// of the whole database the indices refer to.  threads: cores the re-coding loop may take.
+static int build_shard(const int8_t *flat, const uint64_t *offsets, size_t n, const std::vector<uint32_t> &sorted,
+                       const uint32_t *global_index, size_t n_total, int shard_rank, int shard_count, int threads, swg_db **out)
+{
+    swg_db *db = new (std::nothrow) swg_db();
+    if (!db) return swg_set_global_error(SWG_ERR_NOMEM, "swg_db_pack: out of memory");
+    std::unique_ptr<swg_db> holder(db); // freed on every error path, exceptions included
+    db->n_total = n_total;
+    if (n == 0) {
+        derive_tables(db);
+        *out = holder.release();
+        return SWG_OK;
     }
-
     // bins of the global order that belong to this shard
     const size_t n_bins_global = (n + SWG_BIN - 1) / SWG_BIN;
     std::vector<size_t> my_bins;
@@ -127,7 +127,7 @@ static int pack_impl(const int8_t *flat, const uint64_t *offsets, size_t n, cons
     derive_tables(db);
     db->codes.resize(db->code_off.back()); // written completely, sequence by sequence, below
     const long long ns = (long long)(nb * SWG_BIN);
-#pragma omp parallel for schedule(dynamic, 512) num_threads(swg_host_threads())
+#pragma omp parallel for schedule(dynamic, 512) num_threads(threads)
     for (long long s = 0; s < ns; ++s) {
         if (db->order[s] == 0xFFFFFFFFu) continue;
         const int8_t *src = flat + offsets[src_of[s]];
@@ -137,6 +137,62 @@ static int pack_impl(const int8_t *flat, const uint64_t *offsets, size_t n, cons
         for (uint32_t j = len; j < (len + 3) / 4 * 4; ++j) cd[j] = 0; // padding residue up to the dword
     }
     *out = holder.release();
+    return SWG_OK;
+}
+
+static int pack_impl(const int8_t *flat, const uint64_t *offsets, size_t n, const uint32_t *global_index,
+                     size_t n_total, int shard_rank, int shard_count, swg_db **out)
+{
+    if (!out) return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: out is NULL");
+    *out = nullptr;
+    if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count)
+        return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack: bad shard %d/%d", shard_rank,
+                                    shard_count);
+    std::vector<uint32_t> sorted;
+    const int rc = sort_database("swg_db_pack", flat, offsets, n, &sorted);
+    if (rc != SWG_OK) return rc;
+    return build_shard(flat, offsets, n, sorted, global_index, n_total, shard_rank, shard_count, swg_host_threads(), out);
+}
+
+// Every shard of one database from ONE global sort (swg_group_load: one process, several GPUs).  ready(r, db), when
+// given, is called on the thread that built shard r as soon as it is built (the group uploads it from there, so a
+// device's transfer overlaps the other shards' re-coding); its non-zero return stops that shard.  The shards are
+// built side by side, one host thread each, sharing the cores.
+int swg_pack_shards(const int8_t *flat, const uint64_t *offsets, size_t n, int shard_count, swg_db **out,
+                    const std::function<int(int, swg_db *)> &ready)
+{
+    if (!out || shard_count < 1) return swg_set_global_error(SWG_ERR_ARG, "swg_db_pack_shards: bad argument");
+    for (int r = 0; r < shard_count; ++r) out[r] = nullptr;
+    std::vector<uint32_t> sorted;
+    int rc = sort_database("swg_db_pack_shards", flat, offsets, n, &sorted);
+    if (rc != SWG_OK) return rc;
+    const int threads = std::max(1, swg_host_threads() / shard_count);
+    std::vector<int> rcs((size_t)shard_count, SWG_OK);
+    std::vector<std::string> errs((size_t)shard_count);
+    auto work = [&](int r) {
+        try {
+            rcs[r] = build_shard(flat, offsets, n, sorted, nullptr, n, r, shard_count, threads, &out[r]);
+            if (rcs[r] == SWG_OK && ready) rcs[r] = ready(r, out[r]);
+        } catch (const std::exception &e) {
+            rcs[r] = SWG_ERR_NOMEM;
+            errs[r] = e.what();
+        }
+        if (rcs[r] != SWG_OK && errs[r].empty()) errs[r] = swg_global_error(); // (thread-local: carried to the caller's thread below)
+    };
+    std::vector<std::thread> pool;
+    for (int r = 1; r < shard_count; ++r) pool.emplace_back(work, r);
+    work(0);
+    for (std::thread &t : pool) t.join();
+    for (int r = 0; r < shard_count; ++r)
+        if (rcs[r] != SWG_OK) {
+            rc = rcs[r];
+            const std::string msg = errs[r];
+            for (int q = 0; q < shard_count; ++q) {
+                swg_db_free(out[q]);
+                out[q] = nullptr;
+            }
+            return swg_set_global_error(rc, "swg_db_pack_shards: shard %d: %s", r, msg.c_str());
+        }
     return SWG_OK;
 }
 
@@ -172,6 +228,11 @@ extern "C" int swg_db_pack_shard(const int8_t *flat, const uint64_t *offsets, si
     return guarded("swg_db_pack_shard", [&] { return pack_impl(flat, offsets, n_local, global_index, n_total, 0, 1, out); });
 }
 
+extern "C" int swg_db_pack_shards(const int8_t *flat, const uint64_t *offsets, size_t n, int shard_count, swg_db **out)
+{
+    return guarded("swg_db_pack_shards", [&] { return swg_pack_shards(flat, offsets, n, shard_count, out, nullptr); });
+}
+
 // ---------------------------------------------------------------------------
 // packed database file: the host image of a swg_db (sorting and re-coding are the expensive
 // part of ingest), loaded with plain reads afterwards.  Layout: header, order[n_slots],
@@ -198,6 +259,19 @@ template <class V> bool get(FILE *f, V &v, size_t n)
 // side by side, src/alignment_cmdline.c:434,445) back into records laid end to end, padded rows included
 // (the reference computes them as real rows).  first_rec[b] = index of batch b's lane 0 among the records,
 // rec_off = the records' offsets in flat.  All cores: this is most of what the compatibility route costs.
+// The same batches as they are, end to end, into pinned staging (swg_fill_batches16's device route): batches
+// order[lo..hi) to stage + stage_off[batch].  Lives here because this file is compiled by g++ with OpenMP (hipcc
+// compiles swg_api.cpp without it: a pragma there is ignored).
+void swg_stage_batches16(const swg_batch16 *batches, const uint32_t *order, const uint64_t *stage_off, size_t lo, size_t hi,
+                         uint8_t *stage)
+{
+#pragma omp parallel for schedule(dynamic, 16) num_threads(swg_host_threads())
+    for (long long k = (long long)lo; k < (long long)hi; ++k) {
+        const swg_batch16 &bt = batches[order[k]];
+        memcpy(stage + stage_off[order[k]], bt.db_idx_t, (size_t)bt.max_len * 16u);
+    }
+}
+
 void swg_untranspose_batches16(const swg_batch16 *batches, size_t n_batches, const size_t *first_rec,
                                const uint64_t *rec_off, int8_t *flat)
 {

@@ -99,7 +99,7 @@ typedef struct {
  * global rank, so the union of the shards is byte for byte the unsharded database. */
 static int synth_impl(uint64_t seed, size_t n, double median, double sigma_ln, uint32_t min_len,
                       uint32_t max_len, const int8_t *query, size_t lq, double fraction,
-                      double subst, int shard_rank, int shard_count, int8_t **flat_out,
+                      double subst, double subst_hi, int shard_rank, int shard_count, int8_t **flat_out,
                       uint64_t **offsets_out, uint32_t **index_out, size_t *n_local_out,
                       uint64_t *residues_total, size_t *n_planted)
 {
@@ -186,7 +186,9 @@ static int synth_impl(uint64_t seed, size_t n, double median, double sigma_ln, u
         free(gidx);
         return SWG_ERR_NOMEM;
     }
-    const uint64_t sub_thr = (uint64_t)(subst * 65536.0);
+    /* subst_hi > subst: a family of relatives -- every planted sequence draws its own substitution rate from
+     * [subst, subst_hi] (a stream of its own, so that subst_hi == subst is byte for byte the near-copy form) */
+    const int ranged = subst_hi > subst;
 #pragma omp parallel for schedule(dynamic, 256) num_threads(swg_host_threads())
     for (long long i = 0; i < (long long)n_local; i++) {
         const size_t k = gidx ? gidx[i] : (size_t)i; /* global sorted rank: the seed of the sequence */
@@ -197,6 +199,10 @@ static int synth_impl(uint64_t seed, size_t n, double median, double sigma_ln, u
         } else {
             /* copy of the query with point substitutions */
             uint64_t s1 = s0;
+            double rate = subst;
+            if (ranged)
+                rate += (subst_hi - subst) * ((double)(mix(seed ^ 0xFA41u, (uint64_t)k) >> 11) / 9007199254740992.0);
+            const uint64_t sub_thr = (uint64_t)(rate * 65536.0);
             for (size_t j = 0; j < lq; j++) {
                 const uint64_t r = splitmix64(&s1);
                 dst[j] = ((r & 0xFFFF) < sub_thr) ? pick((uint32_t)((r >> 16) & 0xFFFF)) : query[j];
@@ -216,7 +222,7 @@ static int synth_impl(uint64_t seed, size_t n, double median, double sigma_ln, u
 int swg_synth_db(uint64_t seed, size_t n, double median, double sigma_ln, uint32_t min_len,
                  uint32_t max_len, int8_t **flat_out, uint64_t **offsets_out)
 {
-    return synth_impl(seed, n, median, sigma_ln, min_len, max_len, NULL, 0, 0.0, 0.0, 0, 1, flat_out,
+    return synth_impl(seed, n, median, sigma_ln, min_len, max_len, NULL, 0, 0.0, 0.0, 0.0, 0, 1, flat_out,
                       offsets_out, NULL, NULL, NULL, NULL);
 }
 
@@ -225,7 +231,17 @@ int swg_synth_db_similar(uint64_t seed, size_t n, double median, double sigma_ln
                          double subst, int8_t **flat_out, uint64_t **offsets_out, size_t *n_planted)
 {
     if (!query || lq == 0) return SWG_ERR_ARG;
-    return synth_impl(seed, n, median, sigma_ln, min_len, max_len, query, lq, fraction, subst, 0, 1,
+    return synth_impl(seed, n, median, sigma_ln, min_len, max_len, query, lq, fraction, subst, subst, 0, 1,
+                      flat_out, offsets_out, NULL, NULL, NULL, n_planted);
+}
+
+int swg_synth_db_family(uint64_t seed, size_t n, double median, double sigma_ln, uint32_t min_len,
+                        uint32_t max_len, const int8_t *query, size_t lq, double fraction,
+                        double subst_lo, double subst_hi, int8_t **flat_out, uint64_t **offsets_out,
+                        size_t *n_planted)
+{
+    if (!query || lq == 0 || subst_hi < subst_lo || subst_lo < 0.0 || subst_hi > 1.0) return SWG_ERR_ARG;
+    return synth_impl(seed, n, median, sigma_ln, min_len, max_len, query, lq, fraction, subst_lo, subst_hi, 0, 1,
                       flat_out, offsets_out, NULL, NULL, NULL, n_planted);
 }
 
@@ -237,7 +253,7 @@ int swg_synth_db_shard(uint64_t seed, size_t n, double median, double sigma_ln, 
     if (!index_out || !n_local) return SWG_ERR_ARG;
     if (fraction > 0.0 && (!query || lq == 0)) return SWG_ERR_ARG;
     int rc = synth_impl(seed, n, median, sigma_ln, min_len, max_len, fraction > 0.0 ? query : NULL, lq, fraction,
-                        subst, shard_rank, shard_count, flat_out, offsets_out, index_out, n_local,
+                        subst, subst, shard_rank, shard_count, flat_out, offsets_out, index_out, n_local,
                         residues_total, n_planted);
     if (rc == SWG_OK && shard_count == 1 && !*index_out) {
         /* one shard: the identity map, so that callers have one code path */

@@ -18,7 +18,7 @@ def main(budget=300.0, seed=1):
     mats = ["BLOSUM62", "PAM250", "BLOSUM45"]
     t_end = time.time() + budget
     cases = 0
-    forms = {}
+    forms, sizes = {}, {}
     while time.time() < t_end:
         shape = rng.integers(0, 4)
         n = int(rng.integers(1, 2500))
@@ -27,11 +27,18 @@ def main(budget=300.0, seed=1):
         elif shape == 2: lens = np.clip(rng.lognormal(5.0, 0.8, size=n), 1, 3000).astype(np.int64)
         else:            lens = np.concatenate([rng.integers(800, 2500, size=min(n, 2)), rng.integers(1, 150, size=max(0, n - 2))])
         lens = [int(v) for v in lens]
-        nq = int(rng.choice([1, 2, 3, 5, 8, 13, 32, 40]))
+        # odd batches either side of the launch's chunk of 256 queries too: with two queries per lane the last pair of
+        # an odd batch (or of an odd last chunk: 257 = 256 + 1, 513 = 2 * 256 + 1) holds one query twice
+        nq = int(rng.choice([1, 2, 3, 5, 8, 13, 32, 40, 255, 257, 513], p=[.12, .1, .14, .1, .1, .1, .1, .09, .05, .05, .05]))
         base = int(rng.choice([1, 7, 33, 128, 200, 367, 500, 900]))
+        if nq > 200:     # (keeps the oracle's share of a case to seconds)
+            base = int(rng.choice([1, 7, 33, 64]))
+            n = min(n, 600)
+            lens = lens[:n]
         mode = rng.integers(0, 3)
         if mode == 0:   qlens = [base] * nq
         elif mode == 1: qlens = [max(1, int(base * rng.uniform(0.3, 1.2))) for _ in range(nq)]
+        elif nq > 200:  qlens = [int(rng.choice([1, 5, 33, 64, 90])) for _ in range(nq)]
         else:           qlens = [int(rng.choice([5, 64, 300, 1100, 2300])) for _ in range(nq)]   # some need several passes
         if sum(lens) * sum(qlens) > 4e9:
             continue
@@ -75,10 +82,11 @@ def main(budget=300.0, seed=1):
         db.close()
         cases += 1
         forms[int(st["cell_form"])] = forms.get(int(st["cell_form"]), 0) + 1
+        sizes[nq] = sizes.get(nq, 0) + 1
         if cases % 20 == 0:
             print("cases", cases, "last: nq", nq, "qlens", qlens[:4], "n", n, "k", k, "scores", want_scores, "opts", opts, "form", st["cell_form"],
                   "K", st["cols_per_wave"], "G", st["group_lanes"], flush=True)
-    print("OK", cases, "cases; by cell form", dict(sorted(forms.items())))
+    print("OK", cases, "cases; by cell form", dict(sorted(forms.items())), "by batch size", dict(sorted(sizes.items())))
     return 0
 
 

@@ -649,6 +649,80 @@ def test_full_size_databases_equal_the_reference_itself(swg, ctx, orc, cfg):
     assert np.array_equal(orc.score_db(q, b_flat, b_off, tab, -2, -1), scores[big])
 
 
+def test_config4_share_with_relatives_takes_the_flag_and_rerun_route(swg, ctx, orc):
+    """bench.py's block "4_relatives": one GPU's share of config 4 with a seeded 0.5 % of the sequences relatives of
+    the 3000-aa query at 30-70 % identity -- scores about 3 800 .. 10 000, above the f16 cells' ceiling (4096) and
+    below int16's.  The f16 fill flags them, the flagged pairs run again on int16 cells (list mode); first search and
+    steady state return the same scores, every planted sequence's batch and every 16th other batch equal the
+    REFERENCE's own alignment_fill_matrices (scores below 32767: its int16 lanes are exact there), and the cells the
+    fill ran on are reported."""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref was not built (needs the reference sources at build time)")
+    lq, n, seed = 3000, 1250000, 0x5EED0007
+    sc = swg.load_scoring("BLOSUM62")
+    tab = sc.table()
+    q = swg.synth_query(seed, lq)
+    flat, off, planted = swg.synth_db(seed, n, query=q, fraction=0.005, subst=0.3, subst_hi=0.7)
+    assert 5000 < planted < 7500
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    ctx.set_option("autotune", 0)
+    db = swg.Database(flat, off).upload(ctx)
+    first, hits1, st1 = ctx.search(db, k=50)
+    assert st1["path_bits"] == 16 and st1["cell_form"] == 2            # nothing known about this database yet: the f16 cells
+    n_hi = int((first >= 4096).sum())
+    assert st1["n_rescored"] == n_hi and 0.8 * planted < n_hi <= planted + 16   # (a few relatives at 30 % stay below 4096)
+    assert first.max() < 32767
+    again, hits2, st2 = ctx.search(db, k=50)                           # steady state: whatever the library learnt
+    assert np.array_equal(again, first) and hits2 == hits1
+    assert st2["cell_form"] in (0, 2) and (st2["cell_form"] == 0 or st2["n_rescored"] == n_hi)
+    ctx.set_option("f16", 0)                                           # the int16 cells alone, as a third opinion on all of it
+    plain, _, st3 = ctx.search(db)
+    assert st3["cell_form"] == 0 and np.array_equal(plain, first)
+    db.close()
+    _reset_options(ctx)
+    lens = np.diff(off.astype(np.int64))
+    hot = np.unique(np.nonzero(first >= 4096)[0] // 16)
+    groups = np.unique(np.concatenate([hot, np.arange(0, n // 16, 16)]))
+    batches = []
+    for g in groups:
+        o = off[g * 16:g * 16 + 17].astype(np.int64)
+        b = np.full((int(o[1] - o[0]), 16), 31, dtype=np.int8)          # '*' filler, src/alignment_cmdline.c:444-450
+        for l in range(16):
+            b[:int(o[l + 1] - o[l]), l] = flat[int(o[l]):int(o[l + 1])]
+        batches.append(b)
+    ref, _ = orc.ref_batches(q, batches, tab, -2, -1, threads=int(swg.lib.swg_host_threads()))
+    idx = (groups[:, None] * 16 + np.arange(16)[None, :]).ravel()
+    assert np.array_equal(ref.astype(np.int32).ravel(), first[idx])
+    assert hits1 == orc.topk(first, 50) and hits1[0][0] > 9000
+
+
+def test_failed_host_allocation_in_search_end_is_a_status(swg, ctx, orc):
+    """include/swg.h:9-12 on the GPU: the fall-back key vector of swg_search_end (taken when the device top-K cannot be
+    used: here k beyond its candidate capacity) throws std::bad_alloc through the test hook -- the call returns
+    SWG_ERR_NOMEM, the ticket is spent, and the context goes on working."""
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(77, 120)
+    flat, off = swg.synth_db(77, 9000, max_len=400)
+    ctx.set_scoring(sc, -2, -1)
+    ctx.set_query(q)
+    _reset_options(ctx)
+    db = swg.Database(flat, off).upload(ctx)
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    t = ctx.search_begin(db, 6000)                  # k > half the candidate capacity: the host selects from all scores
+    swg.lib.swg_debug_fail_alloc(3)
+    with pytest.raises(swg.SwgError) as e:
+        ctx.search_end(t)
+    swg.lib.swg_debug_fail_alloc(0)
+    assert e.value.code == swg.SWG_ERR_NOMEM and "swg_search_end" in str(e.value)
+    with pytest.raises(swg.SwgError):               # the ticket is spent
+        ctx.search_end(t)
+    got, hits, _ = ctx.search(db, k=6000)
+    assert np.array_equal(got, want) and hits == orc.topk(want, 6000)
+    db.close()
+
+
 def test_long_tail_database(swg, ctx, orc):
     """Swiss-Prot-like tail: a 35,000-residue sequence among short ones (one very long pair,
     odd sequence count, lengths 1 and 2 present), query longer than one pass of some geometries."""

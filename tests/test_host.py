@@ -254,6 +254,56 @@ def test_presharded_pack_equals_sharding_the_whole(swg, tmp_path):
         swg.Database(flat[:int(off[2])], off[:3], index=np.array([0, n], np.uint32), n_total=n)
 
 
+def test_all_shards_from_one_sort(swg, tmp_path):
+    """swg_db_pack_shards (what swg_group_load -- one process, several GPUs -- packs with): shard r is byte for byte
+    swg_db_pack(whole, r, count), and the whole database is sorted ONCE, not once per device."""
+    flat, off = swg.synth_db(33, 1500, max_len=500)
+    for count in (1, 4, 7):
+        before = swg.lib.swg_debug_sort_count()
+        shards = swg.Database.pack_shards(flat, off, count)
+        assert swg.lib.swg_debug_sort_count() == before + 1
+        assert len(shards) == count
+        seen = []
+        for r, b in enumerate(shards):
+            a = swg.Database(flat, off, r, count)
+            assert (a.count, a.total_count, a.residues) == (b.count, b.total_count, b.residues)
+            pa, pb = tmp_path / "a.swg", tmp_path / "b.swg"
+            a.save(str(pa))
+            b.save(str(pb))
+            assert pa.read_bytes() == pb.read_bytes()
+            seen += list(b.order())
+            a.close()
+            b.close()
+        assert sorted(seen) == list(range(1500))
+    bad = flat.copy()
+    bad[17] = 0                                           # the padding residue is refused in input, for every shard at once
+    with pytest.raises(swg.SwgError) as e:
+        swg.Database.pack_shards(bad, off, 4)
+    assert e.value.code == swg.SWG_ERR_RESIDUE
+    empty = swg.Database.pack_shards(np.zeros(0, np.int8), np.zeros(1, np.uint64), 3)
+    assert [d.count for d in empty] == [0, 0, 0]
+
+
+def test_no_exception_crosses_the_search_entry_points(swg):
+    """include/swg.h:9-12: every entry point returns a status.  A failed host allocation inside swg_search_begin /
+    swg_search_end / swg_search (the plan cache is a std::map, the fall-back key list a std::vector) must come back as
+    SWG_ERR_NOMEM, not as std::terminate: the test hook makes the next visit of a site throw std::bad_alloc.
+    (The site inside the fall-back key vector needs a search in flight: tests/test_gpu_parity.py.)"""
+    t = C.c_int(-1)
+    n = C.c_size_t(0)
+    swg.lib.swg_debug_fail_alloc(1)
+    assert swg.lib.swg_search_begin(None, None, 0, 0, C.byref(t)) == swg.SWG_ERR_NOMEM
+    assert b"swg_search_begin" in swg.lib.swg_global_error() and b"memory" in swg.lib.swg_global_error()
+    assert swg.lib.swg_search_begin(None, None, 0, 0, C.byref(t)) == swg.SWG_ERR_ARG      # one shot: the hook is spent
+    swg.lib.swg_debug_fail_alloc(2)
+    assert swg.lib.swg_search_end(None, 0, None, None, C.byref(n), None) == swg.SWG_ERR_NOMEM
+    assert b"swg_search_end" in swg.lib.swg_global_error()
+    swg.lib.swg_debug_fail_alloc(1)
+    assert swg.lib.swg_search(None, None, None, None, 0, C.byref(n), None) == swg.SWG_ERR_NOMEM
+    swg.lib.swg_debug_fail_alloc(0)
+    assert swg.lib.swg_search(None, None, None, None, 0, C.byref(n), None) == swg.SWG_ERR_ARG
+
+
 def test_packed_database_file_roundtrip(swg, tmp_path):
     flat, off = swg.synth_db(5, 700, max_len=300)
     db = swg.Database(flat, off, 1, 2)
@@ -317,6 +367,15 @@ def test_synthetic_data_is_deterministic_and_shaped(swg):
     k = int(np.nonzero(lens == 367)[0][0])
     same = (fs[int(os_[k]):int(os_[k + 1])] == q).mean()
     assert same > 0.9
+    # a family of relatives: every planted sequence with its own substitution rate from the range; the same
+    # sequences are planted, and a range of zero width is the near-copy form byte for byte
+    ff, of, pf = swg.synth_db(7, 500, query=q, fraction=0.1, subst=0.3, subst_hi=0.7)
+    assert pf == planted and np.array_equal(of, os_)
+    ident = [(ff[int(of[k]):int(of[k + 1])] == q).mean() for k in np.nonzero(lens == 367)[0]]
+    ident = [v for v in ident if v > 0.2]                 # (an unplanted sequence of 367 residues matches ~6 %)
+    assert len(ident) == planted and 0.28 < min(ident) < 0.45 and 0.6 < max(ident) < 0.78
+    f0, o0, _ = swg.synth_db(7, 500, query=q, fraction=0.1, subst=0.05, subst_hi=0.05)
+    assert np.array_equal(f0, fs) and np.array_equal(o0, os_)
 
 
 def test_hit_keys_and_merge(swg, orc):
