@@ -128,6 +128,8 @@ def parse_args():
     ap.add_argument("--wide16", type=int, default=-1, help="experiment: 0 = plain int16 cells + int32 re-score instead of the wide form")
     ap.add_argument("--gapopen", type=int, default=-2, help="experiment: gap_open (the configurations use the reference's default -2)")
     ap.add_argument("--gapextend", type=int, default=-1, help="experiment: gap_extend (default -1)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="experiment: any swg_set_option key (repeatable), e.g. --opt batch=0")
     ap.add_argument("--spawn-dry-run", action="store_true",
                     help="--gpus N without a launcher: print the launch command as JSON instead of running it")
     return ap.parse_args()
@@ -210,6 +212,9 @@ def make_context(env, q, sc):
         ctx.set_option("last_pass", a.last_pass)
     if a.wide16 >= 0:
         ctx.set_option("wide16", a.wide16)
+    for kv in a.opt:
+        k, v = kv.split("=", 1)
+        ctx.set_option(k, int(v))
     return ctx
 
 
@@ -420,7 +425,7 @@ def plan_of(last):
             "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
             "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
             "cells": {0: "packed int16", 1: "packed int16, wide form (to 65535)",
-                      2: "packed f16, three-operand maxima (exact below 4096; above: int32 re-score)",
+                      2: "packed f16, three-operand maxima (exact below 4096; flagged pairs run again on int16 cells, int32 only beyond those)",
                       4: "packed f16 for sequences under %d rows, wide int16 form for the longer ones "
                          "(what the f16 cells flag all the same: the wide form again)" % last["split_rows"],
                       5: "packed f16 for sequences under %d rows, packed int16 for the longer ones "

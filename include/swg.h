@@ -65,10 +65,14 @@ typedef struct swg_stats {
     uint64_t cells;         /* lq * sum(len_i): real cells, what GCUPS counts */
     uint64_t cells_padded;  /* cells actually computed (bin + strip padding) */
     uint64_t bytes_alg;     /* algorithmic HBM bytes of the fill */
-    uint64_t n_rescored;    /* sequences that reached the ceiling of the cells they ran on and were run again on wider
-                             * ones (cell_form 2: those the f16 cells flagged; 4, 5: those plus the int16 cells') */
+    uint64_t n_rescored;    /* SEQUENCES that reached the ceiling of the cells they ran on and were run again on wider
+                             * ones.  cell_form 0, 1: those whose int16 / wide score saturated (run again in int32);
+                             * 2: those the f16 cells flagged (score >= 4096; their PAIRS are run again on int16 / wide
+                             * cells, and only what saturates those too goes on to int32 -- not counted a second time);
+                             * 4, 5: the f16 part's flagged sequences plus the int16 / wide part's saturated ones */
     double fill_ms;         /* 16-bit fill kernel (or the int32 fill when forced) */
-    double rescore_ms;      /* overflow collection + int32 re-score */
+    double rescore_ms;      /* everything after the fill that runs flagged work again: collection of the lists, the int16 /
+                             * wide list re-run of what the f16 cells flagged, the int32 re-score */
     double topk_ms;         /* device top-K selection */
     double total_ms;        /* first kernel start .. last kernel end */
     int32_t path_bits;      /* 16 or 32: arithmetic of the main fill */
@@ -94,8 +98,9 @@ typedef struct swg_stats {
      * pass of a very large database is cut into; 1 for a query of one pass */
     int32_t fill_launches;
     /* the cells the 16-bit fill ran on: 0 packed int16 (scores to 32767), 1 the wide int16 form (to 65535),
-     * 2 packed f16 with gfx950's three-operand maxima (exact below 4096; a sequence that reaches it is
-     * flagged and re-scored in int32 like an int16 saturation), 3 (swg_search_multi only) the f16 cells with two
+     * 2 packed f16 with gfx950's three-operand maxima (exact below 4096; a sequence that reaches it is flagged, and
+     * the flagged pairs are run again on the int16 cells -- the wide form if the query can pass 32767 -- by the same
+     * kernel in list mode; int32 only for what saturates those too), 3 (swg_search_multi only) the f16 cells with two
      * QUERIES per lane against one sequence instead of two sequences against one query, 4 both of the 16-bit
      * forms in one search: a query long enough to score beyond 32767 runs the sequences that could reach the f16
      * cells' ceiling -- those of split_rows rows or more -- on the wide form and everything shorter on the f16
@@ -139,15 +144,17 @@ int swg_abi_version(void);
  * 32767 the diagonal engine runs its wide form, exact to 65535, and only scores beyond that are
  * re-scored in int32 | 0: plain int16 and int32 re-score from 32767), "f16" (1 default: the diagonal engine's
  * 16-bit fill runs on packed-f16 cells -- gfx950's three-operand maxima, 8.5 instead of 10 instructions per
- * column pair, exact below 4096, every sequence that reaches 4096 flagged and re-scored in int32 -- unless the
+ * column pair, exact below 4096, every pair with a sequence that reaches 4096 flagged and run again on int16 cells
+ * (two levels: f16 -> int16 / wide -> int32 for what saturates those) -- unless the
  * query is long enough for scores beyond 32767 (then the sequences too short to get there still do and the rest
- * runs on the wide form: swg_stats.cell_form 4) or this database has flagged more than 2 % of its rows for this
- * query | 0: int16 cells only | 2: f16 cells whenever the gap magnitudes are at most 2048), "last_pass" (1 default: the
+ * runs on the wide form: swg_stats.cell_form 4) or the flagged pairs of this database held more than 1/16 of its
+ * pair rows for this query | 0: int16 cells only | 2: f16 cells whenever the gap magnitudes are at most 2048), "last_pass" (1 default: the
  * last pass of a query of several passes runs with the fewest columns per lane that cover what is left | 0: like the
  * other passes), "qq" (1 default: a batch of
  * queries on the f16 cells runs two queries per lane | 0: two sequences per lane as a single query does), "side_readout" (1 default:
  * top-K selection and read-out of a search run on their own stream, beside the fill of the search
- * queued next). */
+ * queued next), "batch" (8 default: pairs one work-queue request claims where pairs are short -- at most
+ * "batch_blocks" (16 default) 4-row token blocks long; 0 / 1: every request claims one pair). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 
 /* Replaces scoring_t for the path (reference src/alignment_scoring.h:21-37):
@@ -209,7 +216,8 @@ const uint32_t *swg_db_order(const swg_db *db);
  *   topk_out/k  NULL/0, or room for k hits of this shard (fewer are written
  *               when the shard is smaller; *n_hits tells how many).
  * Scores are exact int32 local-alignment maxima: the 16-bit kernels flag every
- * sequence whose score reaches their ceiling and those are re-scored in int32. */
+ * sequence whose score reaches their ceiling and those are run again on wider cells
+ * (f16 -> int16 or its wide form -> int32). */
 int swg_search(swg_ctx *ctx, const swg_db *db, int32_t *scores_out,
                swg_hit *topk_out, size_t k, size_t *n_hits, swg_stats *stats);
 

@@ -109,12 +109,47 @@ extern "C" int swg_abi_version(void) { return SWG_ABI_VERSION; }
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+// The long-pair kernel must run BESIDE the bulk kernel: a stream of its own priority level gets its own hardware
+// queue even when other runtimes in the process (RCCL, torch) have used up the default queues, and its workgroups are
+// dispatched first.  Created by the first search whose plan has two classes.
+static int ensure_stream2(swg_ctx *ctx)
+{
+    if (ctx->stream2) return SWG_OK;
+    int least = 0, greatest = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
+    return SWG_OK;
+}
+
+// Top-K and read-out of a finished fill run on a stream of their own, beside the NEXT search's fill: there is no next
+// search before the context's second one, which is when the stream is made (the first search's read-out follows its
+// fill on the fill stream).
+static int ensure_stream3(swg_ctx *ctx)
+{
+    if (ctx->stream3) return SWG_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    return SWG_OK;
+}
+
+// Events and pinned landing buffers of one in-flight search, made when the slot is first used.
+static int ensure_slot(swg_ctx *ctx, SwgSlot *sl)
+{
+    if (sl->ev_done) return SWG_OK;
+    for (auto &ev : sl->ev)
+        if (!ev) HIP_TRY(ctx, hipEventCreate(&ev));
+    if (!sl->h_cand) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl->h_cand), SWG_TOPK_CAND_CAP * 8, hipHostMallocDefault));
+    if (!sl->h_counters) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl->h_counters), 128, hipHostMallocDefault));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming)); // (last: marks the slot complete)
+    return SWG_OK;
+}
+
 extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
 {
     if (!out) return swg_set_global_error(SWG_ERR_ARG, "swg_create: out is NULL");
     *out = nullptr;
     const int dev = cfg ? cfg->device : 0;
     int n = 0;
+    const std::chrono::steady_clock::time_point t_enter = std::chrono::steady_clock::now();
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         return swg_set_global_error(SWG_ERR_NODEVICE,
@@ -127,29 +162,42 @@ extern "C" int swg_create(const swg_config *cfg, swg_ctx **out)
     ctx->device = dev;
     ctx->epoch = g_epoch.fetch_add(1) + 1;
     memset(ctx->sub, 0, sizeof ctx->sub);
+    // SWG_TIMING=1: where the wall time of this call goes (most of a one-shot tool run is here: the HIP runtime's
+    // own start-up, which the first HIP call of the process pays -- hipGetDeviceCount above)
+    typedef std::chrono::steady_clock clk;
+    const bool timing = getenv("SWG_TIMING") != nullptr;
+    clk::time_point tp = clk::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const clk::time_point t = clk::now();
+        fprintf(stderr, "[swg_create] %-44s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count());
+        tp = t;
+    };
+    if (timing) fprintf(stderr, "[swg_create] %-44s %8.2f ms\n", "hipGetDeviceCount (HIP runtime start-up)", std::chrono::duration<double, std::milli>(tp - t_enter).count());
     int rc = [&]() -> int {
         HIP_TRY(ctx, hipSetDevice(dev));
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, dev));
         ctx->n_cu = prop.multiProcessorCount;
+        lap("hipSetDevice + device properties");
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        {
-            // the long-pair kernel must run BESIDE the bulk kernel: a stream of its own priority
-            // level gets its own hardware queue even when other runtimes in the process (RCCL,
-            // torch) have used up the default queues, and its workgroups are dispatched first
-            int least = 0, greatest = 0;
-            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
-        }
-        for (SwgSlot &sl : ctx->slots) {
-            for (auto &ev : sl.ev) HIP_TRY(ctx, hipEventCreate(&ev));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
-            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_cand), SWG_TOPK_CAND_CAP * 8, hipHostMallocDefault));
-            HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_counters), 128, hipHostMallocDefault));
-        }
+        lap("the fill stream");
+        // (the long class's stream and the read-out stream: ensure_stream2 / ensure_stream3, when a search first needs
+        // them -- a stream is ~18 ms of runtime work, and a one-shot tool run is start-up bound)
+        // slot 0 (what swg_search uses); the other in-flight slots get their events and pinned buffers when
+        // swg_search_begin first hands them out (a tool that searches once never pays for them)
+        const int rs = ensure_slot(ctx, &ctx->slots[0]);
+        if (rs != SWG_OK) return rs;
+        lap("events + pinned buffers of one search slot");
         ctx->cur = &ctx->slots[0];
         HIP_TRY(ctx, hipMalloc(&ctx->d_sub, 32 * 32));
+        lap("first device allocation");
+        if (timing) {
+            // the library's code object (~350 kernel instantiations) is loaded by the first launch of any of its kernels
+            HIP_TRY(ctx, swg_launch_zero2(ctx->d_sub, 16, reinterpret_cast<uint8_t *>(ctx->d_sub) + 16, 16, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            lap("first kernel launch (code object load)");
+        }
         return SWG_OK;
     }();
     if (rc != SWG_OK) {
@@ -246,6 +294,14 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         if (value < 0 || value > (long)SWG_DYN_SEG_BLOCKS)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "segment_blocks must be 0 (default) .. 2^26-64");
         ctx->opt_seg_blocks = value ? (uint32_t)value : SWG_DYN_SEG_BLOCKS;
+    } else if (!strcmp(key, "wave_budget")) {
+        ctx->opt_wave_budget = value;
+    } else if (!strcmp(key, "batch")) {
+        if (value < 0 || value > 8) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "batch must be 0..8 (pairs one queue request claims; 0 and 1: one)");
+        ctx->opt_batch = value;
+    } else if (!strcmp(key, "batch_blocks")) {
+        if (value < 1) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "batch_blocks must be >= 1 (token blocks)");
+        ctx->opt_batch_blocks = value;
     } else if (!strcmp(key, "work_queue")) {
         ctx->opt_dynamic = value != 0;
     } else if (!strcmp(key, "prio_share")) {
@@ -695,6 +751,8 @@ static int diag_class_workgroups(const swg_ctx *ctx, const swg_db *db, const Swg
     const SwgKernelInfo info = swg_diag_variant_info(pl.variant);
     const size_t lds = swg_diag_dyn_lds_bytes(pl.K, pl.G, pl.W);
     const int per_cu = std::max(1, std::min<int>(info.max_waves / pl.W, (int)((160 * 1024) / lds)));
+    if (ctx->opt_wave_budget > 0 && wk.n_classes == 1) // experiment: more resident wavefronts than the planner's 16 per CU
+        return std::max(1, ctx->n_cu * std::max(1, std::min<int>((int)ctx->opt_wave_budget / pl.W, (int)((160 * 1024) / lds))));
     const int capacity = ctx->n_cu * per_cu;
     int displaced = 0;
     if (wk.n_classes == 2 && diag_class_is_dynamic(ctx, db, wk.plan[1]))
@@ -780,6 +838,34 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
     return SWG_OK;
 }
 
+// The queue's zones for one launch over pairs [q->q_begin, q->q_end) (see the kernel's event code): the pairs of at most
+// opt_batch_blocks token blocks -- lengths do not increase along the range -- are claimed opt_batch at a time, except
+// the last two per lane group, which go out one by one again so that the lane groups still end together (a claim of
+// B pairs is B times the granularity of the hand-out).  Whole batches only; shard c's first U1 requests are single.
+static void dyn_batch_zones(const swg_ctx *ctx, const SwgPairTokens &T, SwgDiagDynParams *q, uint64_t groups)
+{
+    q->batch_u1 = q->batch_u2 = q->batch_B = 0u;
+    const uint32_t B = (uint32_t)ctx->opt_batch;
+    if (B <= 1u || q->list || q->q_end <= q->q_begin) return;
+    const std::vector<uint32_t> &pre = T.pair_blocks_prefix;
+    const uint32_t N = (uint32_t)std::min<long>(ctx->opt_batch_blocks, 1l << 30);
+    uint32_t lo = q->q_begin, hi = q->q_end; // first pair with at most N blocks
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (pre[mid + 1] - pre[mid] <= N) hi = mid; else lo = mid + 1u;
+    }
+    const uint64_t tail = std::min<uint64_t>(q->q_end - lo, 2ull * groups);
+    const uint64_t to = (uint64_t)q->q_end - tail;
+    const uint64_t u1 = ((uint64_t)(lo - q->q_begin) + SWG_DYN_SHARDS - 1u) / SWG_DYN_SHARDS;
+    const uint64_t p1 = (uint64_t)q->q_begin + SWG_DYN_SHARDS * u1;
+    if (to <= p1) return;
+    const uint64_t u2 = (to - p1) / ((uint64_t)SWG_DYN_SHARDS * B);
+    if (u2 == 0u) return;
+    q->batch_u1 = (uint32_t)u1;
+    q->batch_u2 = (uint32_t)u2;
+    q->batch_B = B;
+}
+
 // Launches the fill of one work plan.  Events: ev[1] before, ev[2] after on the main stream;
 // with a long class also ev[5] (bulk end) and ev[7] (long end).
 static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int go, int ge, bool *two_ends)
@@ -799,6 +885,8 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
         }
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
     if (wk.n_classes == 2) {
+        const int r2 = ensure_stream2(ctx);
+        if (r2 != SWG_OK) return r2;
         // fork: the long pairs start first, on their own stream, beside the bulk
         HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[6], s));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->cur->ev[6], 0));
@@ -902,7 +990,10 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                             q.seg_blocks = T.pair_blocks_prefix[sg.second] - q.seg_origin;
                         }
                         const int variant = pass + 1 == pl.npass && pl.npass > 1 && pl.last_variant >= 0 ? pl.last_variant : pl.variant;
-                        HIP_TRY(ctx, swg_launch_diag_dyn(variant, edges, pform, pl.W, diag_class_workgroups(ctx, db, wk, c), q, qs));
+                        const int wgs_c = diag_class_workgroups(ctx, db, wk, c);
+                        // (with long_helps the long class's kernel reads the bulk's counters too, as single pairs: no zones then)
+                        if (!(ctx->opt_long_helps && wk.n_classes == 2)) dyn_batch_zones(ctx, T, &q, (uint64_t)wgs_c * pl.W * (64 / pl.G));
+                        HIP_TRY(ctx, swg_launch_diag_dyn(variant, edges, pform, pl.W, wgs_c, q, qs));
                         ++launches;
                         if (split && part == 1) ++f16_launches;
                     }
@@ -1238,6 +1329,8 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
     }
     if (timing_events) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
     if (wk.n_classes == 2) {
+        const int r2 = ensure_stream2(ctx);
+        if (r2 != SWG_OK) return r2;
         HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[6], s));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->cur->ev[6], 0));
     }
@@ -1309,7 +1402,13 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
 // many the main fill's own.
 static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess, const SwgDiagPlan &main_plan, SwgDiagPlan *out)
 {
-    if (n_pairs_guess > 4u * (uint32_t)ctx->n_cu) {
+    // 64 lanes per pair: one pair per wavefront, so a list shorter than the launch has lane groups still fills every
+    // wavefront it occupies (with 16-lane groups a list of 3 100 pairs -- config 4's share with 0.5 % relatives --
+    // lands one pair in every fourth group and every wavefront issues its rows for one group in four: 26 ms against
+    // 15), and at 512 columns or more its rows cost the same instructions per pair as the main fill's narrower groups
+    // in more passes (lq 3000: 2 x 269 per pair-row against 6 x 349 / 4).  Only a short query's long list -- where a
+    // 64-lane group would hold two or three columns per lane -- keeps the main fill's geometry.
+    if (n_pairs_guess > 4u * (uint32_t)ctx->n_cu && lq < 512) {
         *out = main_plan;
         out->f16 = 0;
         out->f16_from = 0;
@@ -1607,6 +1706,10 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         return swg_set_ctx_error(ctx, SWG_ERR_STATE, "swg_search: database is not resident on device %d",
                                  ctx->device);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const int rs = ensure_slot(ctx, S);
+        if (rs != SWG_OK) return rs;
+    }
     ctx->cur = S;
     {
         const int rb = select_bufs(ctx, const_cast<swg_db *>(db), (int)(S - ctx->slots));
@@ -1988,10 +2091,16 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     // Top-K and read-out go to their own stream: the next search's fill is queued right behind this
     // one's on the main stream and these small kernels run beside its start instead of holding it
     // up (the output buffers belong to this in-flight slot until swg_search_end).
-    if (ctx->stream3 && ctx->opt_side_readout) {
+    // (the read-out stream exists from the context's second search on: ensure_stream3)
+    S->side = false;
+    if (ctx->opt_side_readout && ctx->n_begun > 0) {
+        const int r3 = ensure_stream3(ctx);
+        if (r3 != SWG_OK) return r3;
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->cur->ev[3], 0));
         s = ctx->stream3;
+        S->side = true;
     }
+    ++ctx->n_begun;
     // top-K on the device unless every score goes to the host anyway
     const bool dev_topk = k > 0 && !want_scores && k <= SWG_TOPK_CAND_CAP / 2;
     if (dev_topk)
@@ -2047,7 +2156,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->cur = S;
-    hipStream_t s = ctx->stream3 && ctx->opt_side_readout ? ctx->stream3 : ctx->stream; // not behind queued fills
+    hipStream_t s = S->side ? ctx->stream3 : ctx->stream; // (the stream this search's read-out was queued on: not behind queued fills)
     for (;;) { // poll: a blocking wait can cost milliseconds of wake-up latency on a busy host
         const hipError_t q = hipEventQuery(S->ev_done);
         if (q == hipSuccess) break;
@@ -2097,8 +2206,11 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
         // what the next search's plan may assume (never its results)
         swg_db *mdb = const_cast<swg_db *>(db);
         mdb->sat_hint = (long long)(S->used_f16 ? h_counters[17] : h_counters[1]); // (f16: pairs; else sequences)
-        // f16 cells that flag more than 1/50 of the rows cost more in re-scores than they save
-        if (S->used_f16 && (uint64_t)h_counters[6] * 16ull * 50ull > db->residues + 2ull * db->n_local) mdb->f16_veto_epoch = S->epoch;
+        // f16 cells whose flagged pairs hold more than 1/16 of the pair rows (counter 6: rows of the flagged pairs / 16;
+        // a pair row is two residues) cost more in re-runs than they save: the cells save 15 % of the fill, the list
+        // re-run of a share f of the rows costs f x 10 / 8.5 at about half the fill's efficiency.  Measured on config
+        // 4's share with 4 % of the pair rows flagged: f16 + re-run 191 ms, int16 cells alone 200.
+        if (S->used_f16 && (uint64_t)h_counters[6] * 16ull * 2ull * 16ull > db->residues + 2ull * db->n_local) mdb->f16_veto_epoch = S->epoch;
     }
     st.classes_overlapped = -1;
     if (use_diag && wk.n_classes == 2 && wk.plan[0].npass == 1 && wk.plan[1].npass == 1) {
@@ -2589,6 +2701,8 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
         }
         HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
         if (wk.n_classes == 2) {
+            const int r2 = ensure_stream2(ctx);
+            if (r2 != SWG_OK) return r2;
             HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[6], s));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->cur->ev[6], 0));
         }
@@ -2648,6 +2762,7 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
             }
             q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
             q.simd_ranks = B.d_cnt + Qb_max * 2 * cnt_class + (size_t)c * SWG_DYN_SIMD_SLOTS;
+            dyn_batch_zones(ctx, T, &q, (uint64_t)wgs[c] * pl.W * (64 / pl.G));
             HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, false, form, pl.W, wgs[c], q, c == 1 ? ctx->stream2 : s, (int)Qb));
         }
         if (wk.n_classes == 2) {

@@ -177,6 +177,7 @@ struct swg_db {
 struct SwgSlot {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_done = nullptr; // polled from user space instead of a blocking stream sync
+    bool side = false;            // this search's top-K and read-out were queued on the read-out stream (stream3)
     bool busy = false;
     const swg_db *db = nullptr;
     swg_db::Bufs bufs; // the output buffers this search writes
@@ -218,6 +219,7 @@ struct swg_ctx {
     hipStream_t stream2 = nullptr; // long-pair kernel runs beside the bulk kernel
     hipStream_t stream3 = nullptr; // top-K and read-out of a finished fill, beside the next search's fill
     int n_cu = 0;
+    unsigned long n_begun = 0; // searches queued so far (the read-out stream is made for the second)
     std::string err;
     // scoring
     bool have_scoring = false;
@@ -233,6 +235,8 @@ struct swg_ctx {
     int query_stage_next = 0;
     // options
     long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 0, opt_wide = 1, opt_side_readout = 1, opt_f16 = 1, opt_qq = 1, opt_last_pass = 1;
+    long opt_wave_budget = 0;
+    long opt_batch = 8, opt_batch_blocks = 16; // work queue: pairs one request claims where pairs are at most that many token blocks long
     uint32_t opt_seg_blocks = SWG_DYN_SEG_BLOCKS; // token blocks per launch of the multi-pass fill (option "segment_blocks": tests)
     // device state
     int8_t *d_sub = nullptr;

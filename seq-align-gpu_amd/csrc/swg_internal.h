@@ -69,6 +69,10 @@ struct SwgDiagDynParams {
     const uint32_t *pair_off; // [n_pairs+1] block offset of each pair's tokens
     uint32_t q_begin, q_end;  // this launch serves pairs [q_begin, q_end) ...
     uint32_t *queue;          // ... handed out by these SWG_DYN_SHARDS counters (zero before the launch)
+    // short pairs by the batch (0, 0, 0: every request claims one pair): after batch_u1 single pairs per shard a
+    // request claims batch_B consecutive pairs, batch_u2 times per shard; what is left of the range goes out one by
+    // one again (see the kernel's event code for the counter -> pair map)
+    uint32_t batch_u1, batch_u2, batch_B;
     // list mode (or null): the counters hand out positions 0 .. *list_count - 1 of `list`, whose entries are pair
     // ids; an entry outside [q_begin, q_end) is skipped (it belongs to another segment's launch).  No second range.
     const uint32_t *list;

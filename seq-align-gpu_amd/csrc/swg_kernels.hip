@@ -853,7 +853,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 //
 // LDS record of a lane group: [0] value of the wavefront's block counter at which
 // the current pair has no more tokens to load (NONE: no pair and none to come),
-// [1] flags, [2] ids pushed, [32..63] ring of pair ids, [64..127] ring of score pairs.
+// [1] flags, [2] ids pushed, [3], [4], [6], [8..16] the group's batch of short pairs (SWG_DYN_MAX_BATCH),
+// [32..63] ring of pair ids, [64..127] ring of score pairs.
 #ifndef SWG_DYN_FENCE_ABOVE
 #define SWG_DYN_FENCE_ABOVE 16 // fence the profile prefetch for K above this
 #endif
@@ -862,6 +863,11 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 // (2*4 + 63) rows / 4 rows per shortest pair = 18 with 64 lanes per pair.
 #define SWG_DYN_RING 32u
 #define SWG_DYN_MAXES 64u
+// Pairs one queue request may claim (swg_diag_dyn_kernel, batch_B): the group's record keeps their block offsets
+// in [8 .. 8 + SWG_DYN_MAX_BATCH], the pairs left in [3], the next id in [4], the batch's first id in [6].
+#ifndef SWG_DYN_MAX_BATCH
+#define SWG_DYN_MAX_BATCH 8u
+#endif
 #ifndef SWG_DYN_TURN_SHIFT
 #define SWG_DYN_TURN_SHIFT 14 // a turn lasts 2^14 ticks of the 100 MHz clock (164 us): long against a block even for the wavefront whose turn it is to yield
 #endif
@@ -950,7 +956,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     {
         uint32_t *st = record();
         if (g < 4) st[g] = 0u; // every group is due at block 0
-        for (uint32_t i = (uint32_t)g; i < 2u * SWG_DYN_RING; i += (uint32_t)G) st[SWG_DYN_MAXES + i] = 0u;
     }
     __syncthreads();
 
@@ -968,7 +973,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     // last row, where the best is being read anyway, instead of on every flagged row: ten instructions fewer per pair and lane)
     uint32_t wipe_next = 0u;
     uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
-    uint32_t nlast = 0u;               // last rows this lane has seen = position of its pair in the group's rings
+    uint32_t nlast = 0u;               // tail lane: last rows it has seen = position of its pair in the group's ring of ids
+    uint32_t bc = Z;                   // the pair's best on its way along the last row (see the flagged-row branch)
     // Tokens: T0..T3 are the rows of the block being worked on.  Each is re-loaded with the same row of
     // the NEXT block right after its use (one block of time for the load to land), from the per-lane
     // pointer tp: the leader's runs through its pair's blocks, everybody else's -- and an idle leader's --
@@ -1042,10 +1048,31 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                 // (one counter for everybody saturates the atomic unit of its memory channel at ~16
                 // requests/us and every request then takes 16 us).  A leader starts at its workgroup's
                 // home shard and moves on when a shard is empty.
+                //
+                // Short pairs by the batch (round 4): a request is an atomic and two dependent loads, 2.2 us during
+                // which the wavefront issues nothing -- and with pairs of a few token blocks (peptides) more than the
+                // pair itself takes, while the counters see hundreds of requests per microsecond.  Where the host says
+                // so (batch_B > 1: the pairs of the range's middle zone are short) one request claims batch_B
+                // consecutive pairs: the leader loads their batch_B + 1 block offsets at once into the group's record
+                // and the next batch_B - 1 hand-outs are two LDS reads.  A counter value u of shard c then means:
+                //   u < U1            pair q_begin + c + 8 u                          (the long pairs, one by one)
+                //   u < U1 + U2       pairs P1 + (8 (u - U1) + c) B .. + B - 1       (P1 = q_begin + 8 U1)
+                //   else              pair P2 + c + 8 (u - U1 - U2)                   (P2 = P1 + 8 U2 B: the last
+                //                     pairs of the range one by one again, so that the lane groups end together)
                 bool second = (fl & SWG_DYN_SECOND) != 0u;
                 uint32_t tried = fl >> 8;
-                uint32_t nq = SWG_DYN_NONE;
+                uint32_t nq = SWG_DYN_NONE, first = 0u, len = 0u;
+                const uint32_t left = p.batch_B > 1u ? st[3] : 0u; // pairs of the group's own batch not handed out yet
+                if (left != 0u) {
+                    nq = st[4];
+                    const uint32_t j = nq - st[6];
+                    first = st[8u + j];
+                    len = st[9u + j] - first;
+                    st[3] = left - 1u;
+                    st[4] = nq + 1u;
+                } else {
                 if (EDGES && (fl & SWG_DYN_IDLING)) tried = SWG_DYN_SHARDS, second = true; // (the queues were empty a block ago)
+                uint32_t claimed = 1u;
                 for (;;) {
                     if (tried >= SWG_DYN_SHARDS) {
                         if (second || p.q2_end <= p.q2_begin) break;
@@ -1067,18 +1094,46 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                         ++tried;
                         continue;
                     }
-                    const uint32_t cand = (second ? p.q2_begin : p.q_begin) + shard + SWG_DYN_SHARDS * atomicAdd(ctr, 1u);
+                    const uint32_t u = atomicAdd(ctr, 1u);
+                    uint32_t cand;
+                    if (second) {
+                        cand = p.q2_begin + shard + SWG_DYN_SHARDS * u;
+                    } else if (u < p.batch_u1 || p.batch_B <= 1u) {
+                        cand = p.q_begin + shard + SWG_DYN_SHARDS * u;
+                    } else if (u - p.batch_u1 < p.batch_u2) {
+                        cand = p.q_begin + SWG_DYN_SHARDS * p.batch_u1 + (SWG_DYN_SHARDS * (u - p.batch_u1) + shard) * p.batch_B;
+                        claimed = p.batch_B; // (whole batches only: the host's U2 ends before the range does)
+                    } else {
+                        cand = p.q_begin + SWG_DYN_SHARDS * (p.batch_u1 + p.batch_u2 * p.batch_B) + shard + SWG_DYN_SHARDS * (u - p.batch_u1 - p.batch_u2);
+                    }
                     if (cand < (second ? p.q2_end : p.q_end)) {
                         nq = cand;
                         break;
                     }
                     ++tried;
                 }
+                if (nq != SWG_DYN_NONE) {
+                    if (claimed > 1u) {
+                        // the batch's block offsets: independent loads, one wait
+                        uint32_t o[SWG_DYN_MAX_BATCH + 1u];
+#pragma unroll
+                        for (uint32_t i = 0u; i <= SWG_DYN_MAX_BATCH; ++i) o[i] = i <= claimed ? p.pair_off[nq + i] : 0u;
+#pragma unroll
+                        for (uint32_t i = 0u; i <= SWG_DYN_MAX_BATCH; ++i) st[8u + i] = o[i];
+                        st[3] = claimed - 1u;
+                        st[4] = nq + 1u;
+                        st[6] = nq;
+                        first = o[0];
+                        len = o[1] - o[0];
+                    } else {
+                        first = p.pair_off[nq];
+                        len = p.pair_off[nq + 1u] - first;
+                    }
+                }
+                }
                 const bool idling = (fl & SWG_DYN_IDLING) != 0u;
                 fl = (second ? SWG_DYN_SECOND : 0u) | (tried << 8);
                 if (nq != SWG_DYN_NONE) {
-                    const uint32_t first = p.pair_off[nq];
-                    const uint32_t len = p.pair_off[nq + 1u] - first;
                     if (EDGES) {
                         efirst = first;
                     } else {
@@ -1234,33 +1289,48 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     go_v = p.go;
                     ge_v = p.ge;
                 }
-                if (tok & SWG_TOK_LAST) {
-                    // the pair's last row on this lane: its maximum joins the pair's slot; the tail lane
-                    // is the last of the group to get here and finishes the pair
-                    uint32_t *st = record();
-                    const uint32_t at = nlast & (SWG_DYN_RING - 1u);
-                    if (F16) wipe_next = cells.best_is_huge();
-                    const uint32_t c = cells.best ^ (F16 ? 0u : Z);
-                    const uint32_t cx = F16 ? f16_key(c & 0xFFFFu) : c & 0xFFFFu, cy = F16 ? f16_key(c >> 16) : c >> 16;
-                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (tail) {
-                        const uint32_t pr = st[SWG_DYN_RING + at];
-                        uint32_t sx = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        uint32_t sy = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at + 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (F16) { // (the LDS maximum was taken on order-preserving keys)
-                            sx = (uint32_t)f16_score(sx);
-                            sy = (uint32_t)f16_score(sy);
-                        }
-                        if (pr >= p.pair_limit) {
-                            // cannot happen with a well-formed token stream; a stray write must not, either
-                        } else if (EDGES) { // one pass of several: the score is the maximum over the passes
-                            atomicMax(scores + 2u * pr, (int)sx);
-                            atomicMax(scores + 2u * pr + 1u, (int)sy);
-                        } else {
-                            scores[2u * pr] = (int)sx;
-                            scores[2u * pr + 1u] = (int)sy;
-                        }
+                // The pair's score.  Every lane holds the maximum of its own columns over the pair (cells.best); on the
+                // pair's LAST row that maximum travels with the row from lane to lane -- bc: what came in from the lane
+                // before, joined with this lane's best -- so the tail lane, the last of the group to see the row, holds
+                // the pair's maximum and writes the two scores.  Only the chain along the last row matters (a lane's bc
+                // is read by its neighbour one step after it was written, on that neighbour's turn at the same row), so
+                // the move and the maximum are made on flagged rows only: two instructions on those, nothing on the
+                // others.  (Round 2-3 joined the bests through two LDS atomics per lane and pair, in a divergent branch
+                // that short pairs -- peptides: 35 rows -- entered on every step: more than half of such a fill.)
+                {
+                    uint32_t cin;
+                    if (G16) {
+                        cin = dpp_keep<DPP_ROW_SHR1>(Z, bc);
+                    } else {
+                        const uint32_t u3 = dpp_keep<DPP_WAVE_SHR1>(Z, bc);
+                        cin = (GW == 32 && leader) ? Z : u3; // lane 32 starts a group too
+                    }
+                    bc = F16 ? pk_max3_f16(cin, cells.best, cells.best) : pk_max_i16(cin, cells.best);
+                }
+                if (F16) {
+                    // all ones in a lane whose best was 32768 or more when its pair ended: wiped on the next reset row
+                    const uint32_t lm = 0u - ((tok >> 17) & 1u);
+                    wipe_next = (wipe_next & ~lm) | (cells.best_is_huge() & lm);
+                }
+                if (tail && (tok & SWG_TOK_LAST) != 0u) {
+                    // the pair's last row at the tail lane: the pair is the next one of the ring
+                    const uint32_t pr = record()[SWG_DYN_RING + (nlast & (SWG_DYN_RING - 1u))];
+                    uint32_t sx, sy;
+                    if (F16) {
+                        sx = (uint32_t)f16_score(f16_key(bc & 0xFFFFu));
+                        sy = (uint32_t)f16_score(f16_key(bc >> 16));
+                    } else {
+                        sx = (bc ^ Z) & 0xFFFFu;
+                        sy = (bc ^ Z) >> 16;
+                    }
+                    if (pr >= p.pair_limit) {
+                        // cannot happen with a well-formed token stream; a stray write must not, either
+                    } else if (EDGES) { // one pass of several: the score is the maximum over the passes
+                        atomicMax(scores + 2u * pr, (int)sx);
+                        atomicMax(scores + 2u * pr + 1u, (int)sy);
+                    } else {
+                        scores[2u * pr] = (int)sx;
+                        scores[2u * pr + 1u] = (int)sy;
                     }
                     ++nlast;
                 }

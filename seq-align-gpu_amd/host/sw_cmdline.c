@@ -21,11 +21,16 @@
 #include "../../include/swg_host.h"
 
 #include <limits.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
 #include <time.h>
+#include <unistd.h>
+#ifndef CLOCK_BOOTTIME
+#define CLOCK_BOOTTIME 7
+#endif
 
 static void usage(const char *argv0, const char *err)
 {
@@ -65,6 +70,60 @@ static double now_ms(void)
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+/* Milliseconds this process had been alive when called (its start time: /proc/self/stat field 22, in clock ticks
+ * since boot): what the dynamic loader and the libraries' static initialisers took before main(). */
+static double ms_since_process_start(void)
+{
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return -1.0;
+    char buf[1024];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')'); /* the command name may hold spaces */
+    if (!p) return -1.0;
+    unsigned long long start = 0;
+    int field = 2;
+    for (p++; *p && field < 22; p++)
+        if (*p == ' ') field++;
+    if (sscanf(p, "%llu", &start) != 1) return -1.0;
+    struct timespec ts;
+    clock_gettime(CLOCK_BOOTTIME, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - (double)start * 1e3 / (double)sysconf(_SC_CLK_TCK);
+}
+
+/* The HIP runtime's start-up (most of a one-shot run: ~200 ms) needs nothing of the input: it runs on a thread of
+ * its own while the main thread reads, converts, sorts and packs the files. */
+typedef struct {
+    swg_config cfg;
+    swg_ctx *ctx;
+    int rc;
+    char err[512];
+    double ms;
+} ctx_job;
+static void *ctx_job_run(void *arg)
+{
+    ctx_job *j = (ctx_job *)arg;
+    const double t0 = now_ms();
+    j->rc = swg_create(&j->cfg, &j->ctx);
+    if (j->rc != SWG_OK) snprintf(j->err, sizeof j->err, "%s", swg_global_error()); /* (thread-local text) */
+    j->ms = now_ms() - t0;
+    return NULL;
+}
+
+static pthread_t g_job_thread;
+static int g_job_started = 0;
+/* every way out of main() after the thread has started waits for it: the process must not run its exit handlers
+ * while another thread is inside the HIP runtime's start-up */
+static int leave(int code)
+{
+    if (g_job_started) {
+        pthread_join(g_job_thread, NULL);
+        g_job_started = 0;
+    }
+    return code;
+}
+
 /* --timing: wall time of the phases the reference leaves out of its `Total Time`, on stderr */
 static int timing = 0;
 static double phase_t0;
@@ -88,6 +147,7 @@ static void die_illegal(char c)
 {
     /* reference src/alignment_scoring.c:78-79 */
     printf("Error: %c is not a legal character for the substitution matrix!\n", c);
+    (void)leave(0);
     exit(1);
 }
 
@@ -182,26 +242,34 @@ int main(int argc, char **argv)
 
     char err[512];
     swg_seqs q, db;
+    if (timing) fprintf(stderr, "[timing] %-28s %9.2f ms\n", "process start to main()", ms_since_process_start());
+    /* one GPU: the context is created beside the reading and packing (several GPUs: swg_group_create, below) */
+    ctx_job job;
+    memset(&job, 0, sizeof job);
+    if (gpus == 0) {
+        job.cfg.device = (int)gpu;
+        g_job_started = pthread_create(&g_job_thread, NULL, ctx_job_run, &job) == 0;
+    }
     phase_t0 = now_ms();
     if (swg_seqs_read(qpath, allq ? 0 : 1, &q, err, sizeof err) != SWG_OK) {
         fprintf(stderr, "Error: couldn't open query file %s\n", qpath);
-        return EXIT_SUCCESS; /* the reference returns from the driver and exits 0 */
+        return leave(EXIT_SUCCESS); /* the reference returns from the driver and exits 0 */
     }
     if (q.n == 0 || q.seq_off[1] == 0) {
         fprintf(stderr, "Error: Query file %s is empty or invalid\n", qpath);
-        return EXIT_SUCCESS;
+        return leave(EXIT_SUCCESS);
     }
     swg_db *pdb = NULL;
     memset(&db, 0, sizeof db);
     if (packed) {
         if (swg_db_load(dbpath, &pdb) != SWG_OK) {
             fprintf(stderr, "Error: %s\n", swg_global_error());
-            return EXIT_SUCCESS;
+            return leave(EXIT_SUCCESS);
         }
         db.n = swg_db_total_count(pdb);
     } else if (swg_seqs_read(dbpath, 0, &db, err, sizeof err) != SWG_OK) {
         fprintf(stderr, "Error: couldn't open database file %s\n", dbpath);
-        return EXIT_SUCCESS;
+        return leave(EXIT_SUCCESS);
     }
     phase(packed ? "read query, load packed db" : "read query and database");
     const size_t lq = (size_t)q.seq_off[1];
@@ -209,7 +277,7 @@ int main(int argc, char **argv)
     int8_t *didx = (int8_t *)malloc(db.n && !packed ? (size_t)db.seq_off[db.n] + 1 : 1);
     if (!qidx || !didx) {
         fprintf(stderr, "Error: out of memory\n");
-        return EXIT_FAILURE;
+        return leave(EXIT_FAILURE);
     }
     char bad = 0;
     {
@@ -225,7 +293,7 @@ int main(int argc, char **argv)
     swg_hit *hits = (swg_hit *)calloc(topk ? (size_t)topk : 1, sizeof(swg_hit));
     if (!scores || !hits) {
         fprintf(stderr, "Error: out of memory\n");
-        return EXIT_FAILURE;
+        return leave(EXIT_FAILURE);
     }
     size_t n_hits = 0;
     double total_ms = 0.0;
@@ -234,11 +302,11 @@ int main(int argc, char **argv)
     if (gpus > 0) {
         /* database sharded over several GPUs of this process */
         swg_stats *st = (swg_stats *)calloc((size_t)gpus, sizeof(swg_stats));
-        if (!st) return EXIT_FAILURE;
+        if (!st) return leave(EXIT_FAILURE);
         int rc = swg_group_create(NULL, (int)gpus, 0, &grp);
         if (rc != SWG_OK) {
             fprintf(stderr, "Error: %s\n", swg_global_error());
-            return EXIT_FAILURE;
+            return leave(EXIT_FAILURE);
         }
         phase("create contexts");
         /* one search per query length: timing candidate geometries first would cost more than it saves */
@@ -251,35 +319,40 @@ int main(int argc, char **argv)
         phase("search");
         if (rc != SWG_OK) {
             fprintf(stderr, "Error: %s\n", swg_group_last_error(grp));
-            return EXIT_FAILURE;
+            return leave(EXIT_FAILURE);
         }
         for (long g = 0; g < gpus; g++)
             if (st[g].total_ms > total_ms) total_ms = st[g].total_ms; /* the GPUs run side by side */
         free(st);
     } else {
-        swg_config cfg;
-        memset(&cfg, 0, sizeof cfg);
-        cfg.device = (int)gpu;
-        if (swg_create(&cfg, &ctx) != SWG_OK) {
-            fprintf(stderr, "Error: %s\n", swg_global_error());
-            return EXIT_FAILURE;
-        }
-        phase("create context");
         swg_stats st;
         memset(&st, 0, sizeof st);
-        /* one search per query length: timing candidate geometries first would cost more than it saves */
-        int rc = swg_set_option(ctx, "autotune", 0);
-        if (rc == SWG_OK) rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
-        if (rc == SWG_OK) rc = swg_set_query(ctx, qidx, lq);
-        if (rc == SWG_OK && !packed) {
+        int rc = SWG_OK;
+        if (!packed) { /* host only: still beside the context's creation */
             rc = swg_db_pack(didx, db.seq_off, db.n, 0, 1, &pdb);
             if (rc != SWG_OK) fprintf(stderr, "Error: %s\n", swg_global_error());
             phase("sort and pack");
         }
+        if (g_job_started) {
+            (void)leave(0);
+        } else {
+            ctx_job_run(&job);
+        }
+        ctx = job.ctx;
+        if (job.rc != SWG_OK) {
+            fprintf(stderr, "Error: %s\n", job.err);
+            return leave(EXIT_FAILURE);
+        }
+        if (timing) fprintf(stderr, "[timing] %-28s %9.2f ms (on its own thread, beside the phases above)\n", "create context", job.ms);
+        phase("wait for the context");
+        /* one search per query length: timing candidate geometries first would cost more than it saves */
+        if (rc == SWG_OK) rc = swg_set_option(ctx, "autotune", 0);
+        if (rc == SWG_OK) rc = swg_set_scoring(ctx, (const int8_t(*)[32])sc.sub, sc.gap_open, sc.gap_extend);
+        if (rc == SWG_OK) rc = swg_set_query(ctx, qidx, lq);
         if (rc == SWG_OK && savedb) {
             if (swg_db_save(pdb, savedb) != SWG_OK) {
                 fprintf(stderr, "Error: %s\n", swg_global_error());
-                return EXIT_FAILURE;
+                return leave(EXIT_FAILURE);
             }
             fprintf(stderr, "packed database written to %s\n", savedb);
         }
@@ -289,7 +362,7 @@ int main(int argc, char **argv)
         phase("search (first of this database)");
         if (rc != SWG_OK) {
             fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
-            return EXIT_FAILURE;
+            return leave(EXIT_FAILURE);
         }
         total_ms = st.total_ms;
     }
@@ -334,11 +407,11 @@ next_query:
         swg_alignment *al = (swg_alignment *)calloc(n_hits, sizeof *al);
         char *ops = (char *)malloc(n_hits * stride);
         char *line = (char *)malloc(stride);
-        if (!al || !ops || !line) return EXIT_FAILURE;
+        if (!al || !ops || !line) return leave(EXIT_FAILURE);
         if ((grp ? swg_group_align_hits(grp, hits, n_hits, al, ops, stride)
                  : swg_align_hits(ctx, pdb, hits, n_hits, al, ops, stride)) != SWG_OK) {
             fprintf(stderr, "Error: %s\n", grp ? swg_group_last_error(grp) : swg_last_error(ctx));
-            return EXIT_FAILURE;
+            return leave(EXIT_FAILURE);
         }
         for (size_t i = 0; i < n_hits; i++) {
             const swg_alignment *a = &al[i];
@@ -390,13 +463,13 @@ next_query:
             mq_scores = (int32_t *)calloc(chunk_n * (db.n ? db.n : 1), sizeof(int32_t));
             mq_hits = (swg_hit *)calloc(chunk_n * (topk ? (size_t)topk : 1), sizeof(swg_hit));
             mq_nhits = (size_t *)calloc(chunk_n, sizeof(size_t));
-            if (!qx || !qoff || !mq_scores || !mq_hits || !mq_nhits) return EXIT_FAILURE;
+            if (!qx || !qoff || !mq_scores || !mq_hits || !mq_nhits) return leave(EXIT_FAILURE);
             for (size_t i = 0; i <= chunk_n; i++) qoff[i] = q.seq_off[chunk_first + i] - q.seq_off[chunk_first];
             for (size_t i = 0; i < chunk_n; i++) {
                 const size_t lqi = (size_t)(qoff[i + 1] - qoff[i]);
                 if (lqi == 0) {
                     fprintf(stderr, "Error: query #%lu is empty\n", (unsigned long)(chunk_first + i));
-                    return EXIT_FAILURE;
+                    return leave(EXIT_FAILURE);
                 }
                 for (size_t c = 0; c < lqi; c++) {
                     const char ch = q.seq[q.seq_off[chunk_first + i] + c];
@@ -411,7 +484,7 @@ next_query:
             const int rc = swg_search_multi(ctx, pdb, qx, qoff, chunk_n, mq_scores, mq_hits, (size_t)topk, mq_nhits, &st);
             if (rc != SWG_OK) {
                 fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
-                return EXIT_FAILURE;
+                return leave(EXIT_FAILURE);
             }
             chunk_ms = st.total_ms / (double)chunk_n; /* the chunk's device time, shared out over its queries */
             if (timing)
@@ -425,7 +498,7 @@ next_query:
         if (align && swg_set_query(ctx, qx + qoff[at], (size_t)(qoff[at + 1] - qoff[at])) != SWG_OK) {
             /* (the alignments of the hits are made against the context's query) */
             fprintf(stderr, "Error: %s\n", swg_last_error(ctx));
-            return EXIT_FAILURE;
+            return leave(EXIT_FAILURE);
         }
         total_ms = chunk_ms;
         qname = q.names + q.name_off[qi];
@@ -442,5 +515,6 @@ next_query:
     free(didx);
     free(scores);
     free(hits);
-    return EXIT_SUCCESS;
+    phase("release (context, buffers)");
+    return leave(EXIT_SUCCESS);
 }

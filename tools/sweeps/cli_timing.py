@@ -28,12 +28,18 @@ for extra in ([], ["--topk", "100", "--align"], ["--savedb", "/tmp/cli/db.swg"],
     for rep in range(2):
         t0 = time.time()
         r = subprocess.run([cli, "--substitution_matrix", mat, "--timing"] + extra + ["--files", "/tmp/cli/q.fa", dbf],
-                           stdout=open("/tmp/cli/out.txt", "wb"), stderr=subprocess.PIPE, text=True)
+                           stdout=open("/tmp/cli/out.txt", "wb"), stderr=subprocess.PIPE, text=True,
+                           env=dict(os.environ, SWG_TIMING="1") if not extra else None)   # (plain run: swg_create's own breakdown too)
         wall = time.time() - t0
     print("== %s: exit %d, wall %.0f ms (second run), stdout %.1f MB" % (" ".join(extra) or "plain", r.returncode, wall * 1e3,
                                                                     os.path.getsize("/tmp/cli/out.txt") / 1e6))
     print(r.stderr, flush=True)
     print(subprocess.run(["tail", "-2", "/tmp/cli/out.txt"], stdout=subprocess.PIPE, text=True).stdout if not extra else "", flush=True)
+# what the dynamic loader does before main(): relocation statistics of the same command
+r = subprocess.run([cli, "--help"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=dict(os.environ, LD_DEBUG="statistics"))
+print("== LD_DEBUG=statistics (smith_waterman --help)")
+print("\n".join(l for l in r.stderr.splitlines() if "total startup time" in l or "time needed for relocation" in l or "time needed to load objects" in l or "number of relocations:" in l))
+t0 = time.time(); subprocess.run([cli, "--help"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); print("wall of --help (load + static initialisers + exit): %.0f ms" % ((time.time() - t0) * 1e3))
 print("host threads used by the library: %d; os.cpu_count %d; affinity %d" %
       (swg.lib.swg_host_threads(), os.cpu_count(), len(os.sched_getaffinity(0))))
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
