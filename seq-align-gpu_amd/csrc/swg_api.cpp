@@ -294,6 +294,8 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         if (value < 0 || value > (long)SWG_DYN_SEG_BLOCKS)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "segment_blocks must be 0 (default) .. 2^26-64");
         ctx->opt_seg_blocks = value ? (uint32_t)value : SWG_DYN_SEG_BLOCKS;
+    } else if (!strcmp(key, "q32_waves")) {
+        ctx->opt_q32_waves = value;
     } else if (!strcmp(key, "wave_budget")) {
         ctx->opt_wave_budget = value;
     } else if (!strcmp(key, "batch")) {
@@ -1135,6 +1137,11 @@ static void q32_occupancy(const swg_ctx *ctx, const SwgDiagWork &wk, int *bulk_W
             best_W = W;
             best_n = n;
         }
+    }
+    if (ctx->opt_q32_waves > 0 && ctx->opt_q32_waves <= info.max_waves && wk.n_classes == 1 &&
+        swg_diag32q_lds_bytes(pl.K, pl.G, (int)ctx->opt_q32_waves) <= room) { // experiment: the workgroup size of an int32 launch
+        best_W = (int)ctx->opt_q32_waves;
+        best_n = std::max(1, std::min<int>((int)(room / swg_diag32q_lds_bytes(pl.K, pl.G, best_W)), cap_waves / best_W));
     }
     *bulk_W = best_W;
     *bulk_per_cu = best_n;

@@ -26,21 +26,25 @@ def _check_block(b, n_gpus=1):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The default one-GPU line: headline = config 3, one block per configuration 2, 3, 4 (share), 5, and
-    the whole 10M-sequence config 4 as the N = 1 point of the scaling curve."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
+    """The default one-GPU line: headline = config 4's ONE 10M-sequence database whole on the GPU -- the workload
+    `--gpus N` deals over N ranks -- and one block per configuration 3, 2, 4 (share), 4 with relatives, 5, 5 stress."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                  ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("configs", dict)):
         assert isinstance(d[k], t), k
     assert d["vs_baseline"] is None and d["scaling"] == "strong" and d["higher_is_better"] is True
-    assert d["unit"] == "GCUPS" and d["data"] == "synthetic"
-    assert d["config"]["workload"].startswith("config 3:") and d["config"]["n_seqs"] == 570000
+    assert d["unit"] == "GCUPS" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert d["config"]["workload"].startswith("config 4:") and "ONE" in d["config"]["workload"]
+    assert d["config"]["n_seqs"] == 10000000 and d["config"]["lq"] == 3000
+    assert d["roofline"]["launches_per_step"] == 48 and d["roofline"]["traffic_source"].endswith("#config4_whole_f16")
     _check_block(d)
-    assert set(d["configs"]) == {"2", "3", "4", "5", "5_stress"}
+    assert set(d["configs"]) == {"2", "3", "4", "4_relatives", "4_whole", "5", "5_stress"}
+    names = {"5_stress": "5 (stress variant)", "4_relatives": "4 (relatives)", "4_whole": "4"}
     for k, b in d["configs"].items():
-        assert b["config"]["workload"].startswith("config %s:" % k.replace("_stress", " (stress variant)"))
+        assert b["config"]["workload"].startswith("config %s:" % names.get(k, k))
         _check_block(b)
+    assert d["configs"]["4_whole"]["value"] == d["value"]
     # the stress variant of config 5 (SURVEY 8d): every one of its 100 000 sequences re-scored in the `rescore` leg
     cs = d["configs"]["5_stress"]
     assert cs["config"]["n_seqs"] == 100000 and cs["rescore"]["n_rescored"] == 100000 and cs["rescore"]["top_k_equals_main_leg"]
@@ -48,22 +52,41 @@ def test_committed_bench_line_has_the_contract_fields():
     r5 = d["configs"]["5"]["roofline"]["binding_roof"]
     assert d["configs"]["5"]["dtype"] == "f16+int16" and abs(r5["cells_share"] + r5["other_kernel"]["cells_share"] - 1.0) < 1e-3
     assert 0.5 < r5["frac_of_issue_peak"] <= 1.0 and 0.5 < r5["other_kernel"]["frac_of_issue_peak"] <= 1.0
-    assert d["configs"]["3"]["value"] == d["value"]
     # config 5 as BASELINE names it: one GPU's share of the 10M-sequence shape, and a leg that really re-scores
     c5 = d["configs"]["5"]
     assert c5["config"]["n_seqs"] == 1250000 and c5["rescore"]["n_rescored"] > 0 and c5["rescore"]["top_k_equals_main_leg"]
     assert c5["rescore"]["kernel_ms"]["rescore"] > 0 and c5["rescore"]["options"] == {"wide16": 0}
-    for b in (d, d["configs"]["2"], d["configs"]["4"], d["scaling_reference"]):
+    # config 4's share with a family of relatives: the f16 flag-and-re-run route is really taken, first search and after
+    cr = d["configs"]["4_relatives"]
+    assert cr["config"]["n_seqs"] == 1250000 and cr["first_search"]["n_rescored"] > 0 and cr["first_search"]["cell_form"] == 2
+    assert cr["steady_state"]["n_rescored"] == cr["first_search"]["n_rescored"] and cr["steady_state"]["rescore_ms"] > 0
+    assert cr["kernel_ms"]["rescore"] > 0 and cr["verify"]["ok"] is True
+    for b in (d, d["configs"]["2"], d["configs"]["3"], d["configs"]["4"]):
         assert b["dtype"] == "f16" and b["roofline"]["binding_roof"]["instr_per_cell"] == 4.25
         assert b["roofline"]["traffic"] is None or b["roofline"]["traffic_source"].startswith("profiles/traffic.json@sha256:")
-    ref = d["scaling_reference"]
-    assert ref["config"]["n_seqs"] == 10000000 and "ONE" in ref["config"]["workload"]
-    _check_block(ref)
     c = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample", "cpu_model", "one_thread_gcups")) <= set(c)
     assert c["kind"] in ("reference", "port")
     h = d["host_inclusive"]
     assert h["upload_bytes"] < 1.1 * d["configs"]["2"]["config"]["residues_total"]     # about one byte per residue
+
+
+def test_every_point_of_the_scaling_curve_is_the_same_workload():
+    """value(N) / (N * value(1)) is only a scaling efficiency if N = 1 and N > 1 run the same
+    workload.  `bench.py --gpus 1` and the one-rank run of the N > 1 path (SWG_BENCH_FORCE_DIST=1: launcher, RCCL
+    communicator, all-reduce merge) on the same box name the same database and agree within 1 %."""
+    one = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    dist = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_dist_rehearsal_1gpu.json")))
+    for k in ("workload", "lq", "n_seqs", "residues_total", "matrix"):
+        assert one["config"][k] == dist["config"][k], k
+    assert one["metric"] == dist["metric"] and one["scaling"] == dist["scaling"] == "strong"
+    assert one["steps"] == dist["steps"] and one["warmup"] == dist["warmup"]
+    assert abs(one["value"] - dist["value"]) < 0.01 * one["value"]
+    assert one["roofline"]["launches_per_step"] == dist["roofline"]["launches_per_step"] == 48
+    # and the code path: both go through run_config(..., sharded=True) on config 4's full size
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count('run_config(env, SHARDED, K, W, sharded=True, n_override=CONFIGS[SHARDED]["n_full"], cpu_leg=True)') == 1
+    assert "run_config(env, cnum, K, W, sharded=True, n_override=n_full, cpu_leg=True)" in src
 
 
 def test_bench_help_and_launch_rule_need_no_gpu():
