@@ -119,6 +119,9 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the top-K check against the oracle (outside the timed region)")
     ap.add_argument("--no-scaling-reference", action="store_true", help="(accepted and ignored: the 10M-sequence database is the headline now)")
     ap.add_argument("--only-headline", action="store_true", help="one GPU: the headline configuration alone")
+    ap.add_argument("--whole", action="store_true",
+                    help="one GPU, with --config 4 or 5: the configuration's WHOLE 10M-sequence database through the sharded path "
+                         "with one shard -- the N = 1 point of the curve `--gpus N --config C` continues")
     ap.add_argument("--max-len", type=int, default=0, help="diagnostic: clamp the sequence lengths here (default 5000)")
     ap.add_argument("--uniform-len", type=int, default=0,
                     help="diagnostic: every sequence gets this length (no length tail)")
@@ -826,6 +829,11 @@ def main():
         block = run_config(env, cnum, K, W, sharded=True, n_override=n_full, cpu_leg=True)
         if env.rank == 0:
             emit(line_from(block, env, "strong"))
+    elif args.config and args.whole and CONFIGS[args.config].get("n_full"):
+        block = run_config(env, args.config, K, W, sharded=True, n_override=args.nseq or CONFIGS[args.config]["n_full"], cpu_leg=True)
+        out = line_from(block, env, "strong")
+        out["configs"] = {"%d_whole" % args.config: {k: v for k, v in block.items() if k != "cpu_baseline"}}
+        emit(out)
     elif args.config:
         block = run_config(env, args.config, K, W, host_inclusive_leg=True, cpu_leg=True,
                            legs=CONFIG_LEGS.get(args.config, ()))

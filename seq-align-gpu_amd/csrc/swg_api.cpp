@@ -931,6 +931,8 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
             }
             q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
             q.simd_ranks = db->d_counters + SWG_RANK_WORD(c);
+            // (f16 sums round to nearest: a computed 32768 needs a true score within a few units of it)
+            q.f16_wipe = ctx->cur->score_bound >= 32000ull ? 1u : 0u;
             q.trace = d_trace[c];
             // start / end wall-clock stamps of single-pass launches: words 8..15 of the counters
             q.stamps = pl.npass == 1 ? reinterpret_cast<unsigned long long *>(db->d_counters + 8 + 4 * c) : nullptr;
@@ -1760,6 +1762,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     }
     const uint64_t longest = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK;
     const uint64_t score_bound = std::min<uint64_t>(qbound, std::min<uint64_t>(lq, longest) * (uint64_t)smax);
+    S->score_bound = score_bound;
     bool wide = bits == 16 && score_bound >= 32767ull && ctx->opt_engine != 1 && ctx->opt_wide != 0;
     // The packed-f16 cells (three-operand maxima, 8.5 instead of 10 instructions per column pair) are exact
     // while scores stay below 4096; a sequence that reaches it is flagged and re-scored in int32.  They are the

@@ -177,6 +177,7 @@ struct swg_db {
 struct SwgSlot {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_done = nullptr; // polled from user space instead of a blocking stream sync
+    uint64_t score_bound = ~0ull; // the largest score this search's query can reach against this database (launch_diag: f16_wipe)
     bool side = false;            // this search's top-K and read-out were queued on the read-out stream (stream3)
     bool busy = false;
     const swg_db *db = nullptr;

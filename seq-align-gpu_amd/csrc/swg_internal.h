@@ -73,6 +73,9 @@ struct SwgDiagDynParams {
     // request claims batch_B consecutive pairs, batch_u2 times per shard; what is left of the range goes out one by
     // one again (see the kernel's event code for the counter -> pair map)
     uint32_t batch_u1, batch_u2, batch_B;
+    // f16 cells: 1 = a score of this search may reach 32768, beyond which two reset rows no longer clear a lane's state:
+    // lanes test their best on reset rows and wipe by hand (0: no score can get there, the test is skipped)
+    uint32_t f16_wipe;
     // list mode (or null): the counters hand out positions 0 .. *list_count - 1 of `list`, whose entries are pair
     // ids; an entry outside [q_begin, q_end) is skipped (it belongs to another segment's launch).  No second range.
     const uint32_t *list;

@@ -969,9 +969,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
     uint32_t em_rot[2] = {Z, Z}, eb_rot[2] = {Z, Z};
     uint32_t zero_v = Z; // (F16: the floor operand of the maxima, kept in a register)
     asm volatile("" : "+v"(zero_v));
-    // F16: all ones in a lane whose running best was 32768 or more when its pair ended (looked at once per pair, on the
-    // last row, where the best is being read anyway, instead of on every flagged row: ten instructions fewer per pair and lane)
-    uint32_t wipe_next = 0u;
     uint32_t go_v = p.go, ge_v = p.ge; // per-lane gap magnitudes: all ones while the lane is on a reset row
     uint32_t nlast = 0u;               // tail lane: last rows it has seen = position of its pair in the group's ring of ids
     uint32_t bc = Z;                   // the pair's best on its way along the last row (see the flagged-row branch)
@@ -1257,11 +1254,13 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                     const uint32_t fw = fm & (((tok >> 19) & 1u) - 1u);
                     if (__builtin_amdgcn_ballot_w64(fw != 0u) != 0ull) cells.wipe(fw);
                 } else if (F16) {
-                    // (two rows at 65504 clear any state below 32768; a lane that got beyond is wiped by hand)
-                    const uint32_t fi = fm & wipe_next;
-                    if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) {
-                        cells.wipe(fi);
-                        wipe_next &= ~fi;
+                    // (two rows at 65504 clear any state below 32768; a lane that got beyond is wiped by hand: its best
+                    // -- still the ended pair's on the first reset row, nothing has grown it since that pair's last
+                    // row -- is 32768 or more; on the second reset row the best is what the first left: small)
+                    // -- and only a launch whose query can score that much looks at all (p.f16_wipe, a scalar test).
+                    if (p.f16_wipe) {
+                        const uint32_t fi = fm & cells.best_is_huge();
+                        if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) cells.wipe(fi);
                     }
                     cells.best = (cells.best & ~fm) | (Z & fm);
                     go_v = (go_v & ~fm) | (SWG_F16_BIG & fm);
@@ -1306,11 +1305,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
                         cin = (GW == 32 && leader) ? Z : u3; // lane 32 starts a group too
                     }
                     bc = F16 ? pk_max3_f16(cin, cells.best, cells.best) : pk_max_i16(cin, cells.best);
-                }
-                if (F16) {
-                    // all ones in a lane whose best was 32768 or more when its pair ended: wiped on the next reset row
-                    const uint32_t lm = 0u - ((tok >> 17) & 1u);
-                    wipe_next = (wipe_next & ~lm) | (cells.best_is_huge() & lm);
                 }
                 if (tail && (tok & SWG_TOK_LAST) != 0u) {
                     // the pair's last row at the tail lane: the pair is the next one of the ring

@@ -59,6 +59,7 @@ def main(budget=300.0, seed=1):
         for k in ("work_queue", "wide16", "autotune", "side_readout", "f16", "last_pass"):
             ctx.set_option(k, 1)
         ctx.set_option("long_helps", 0)
+        ctx.set_option("batch", 8); ctx.set_option("batch_blocks", 16)
         opts = {}
         r = rng.random()
         if r < 0.25:
@@ -79,6 +80,10 @@ def main(budget=300.0, seed=1):
         if rng.random() < 0.2: opts["autotune"] = 0
         if rng.random() < 0.2: opts["last_pass"] = 0   # every pass of a long query with the same columns per lane
         if rng.random() < 0.15: opts["wide16"] = 0
+        # the work queue's batches: off, small, and thresholds from "no pair is short" to "every pair is" (a claim of
+        # eight LONG pairs is legal, only slow)
+        if rng.random() < 0.3: opts["batch"] = int(rng.choice([0, 2, 5, 8]))
+        if rng.random() < 0.3: opts["batch_blocks"] = int(rng.choice([1, 4, 64, 100000]))
         if rng.random() < 0.25:   # multi-pass launches cut into segments of consecutive pairs (never shorter than a pair)
             opts["segment_blocks"] = int((max(lens) + 5) // 4 * rng.choice([1, 2, 7]) + rng.integers(0, 3))
         if "cols_per_wave" in opts and opts["cols_per_wave"] * opts["group_lanes"] * 64 > 150 * 1024:

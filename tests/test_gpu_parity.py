@@ -21,6 +21,8 @@ DEFAULT_OFF = ("long_helps",)
 
 
 def _reset_options(ctx):
+    ctx.set_option("batch", 8)
+    ctx.set_option("batch_blocks", 16)
     for k in OPTIONS:
         ctx.set_option(k, 0)
     for k in DEFAULT_ON:
@@ -790,6 +792,62 @@ def test_work_queue_variants_agree(swg, ctx, orc):
             assert np.array_equal(got2, want), (name, opts, "second search")
             db.close()
     _reset_options(ctx)
+
+
+def test_pairs_claimed_by_the_batch(swg, ctx, orc):
+    """Round 4: where pairs are short one queue request claims `batch` consecutive pairs (three zones per shard: single
+    long pairs, whole batches, the last pairs single again).  Batch sizes, thresholds from "no pair counts as short" to
+    "every pair does", a long class in front (the range does not begin at pair 0), several passes cut into segments
+    (ranges that begin and end anywhere), fewer pairs than one batch per shard, and batches of queries: always the
+    oracle's scores.  Peptide-like and tiny pairs, odd counts."""
+    sc = swg.load_scoring("BLOSUM62")
+    rng = np.random.default_rng(77)
+    shapes = {
+        "peptides": [int(v) for v in rng.integers(20, 41, size=30001)],
+        "tiniest": [1, 2, 3] * 9000 + [1],
+        "few": [int(v) for v in rng.integers(5, 30, size=37)],              # less than one batch per shard
+        "mixed": [3000, 1800, 900] + [int(v) for v in rng.integers(1, 400, size=9000)],
+    }
+    ctx.set_scoring(sc, -2, -1)
+    for name, lens in shapes.items():
+        seqs = [swg.synth_query(5000 + i, L) for i, L in enumerate(lens)]
+        flat = np.concatenate(seqs)
+        off = np.zeros(len(lens) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        for lq in (30, 700):
+            q = swg.synth_query(9 + lq, lq)
+            ctx.set_query(q)
+            want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+            for opts in ({}, {"batch": 0}, {"batch": 2}, {"batch": 5, "batch_blocks": 3}, {"batch_blocks": 100000},
+                         {"batch_blocks": 100000, "long_split": 200}, {"batch_blocks": 64, "long_split": 200, "long_helps": 1},
+                         {"cols_per_wave": 8, "group_lanes": 16, "max_waves": 4, "segment_blocks": 4000, "batch_blocks": 100000},
+                         {"cols_per_wave": 4, "group_lanes": 64, "max_waves": 4, "batch": 8, "batch_blocks": 12},
+                         {"f16": 0, "batch_blocks": 9}):
+                if lq == 30 and "segment_blocks" in opts:
+                    continue                                                     # (several passes need a query beyond G * K columns)
+                _reset_options(ctx)
+                ctx.set_option("autotune", 0)
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                db = swg.Database(flat, off).upload(ctx)
+                got, hits, st = ctx.search(db, k=5)
+                assert np.array_equal(got, want), (name, lq, opts, st)
+                assert hits == orc.topk(want, 5)
+                db.close()
+        if name in ("peptides", "tiniest"):                                      # batches of queries share the zones
+            _reset_options(ctx)
+            qs = [swg.synth_query(600 + i, L) for i, L in enumerate((30, 64, 17))]
+            db = swg.Database(flat, off).upload(ctx)
+            for opts in ({}, {"batch_blocks": 100000}, {"qq": 0, "batch": 3}):
+                _reset_options(ctx)
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                got, _, st = ctx.search_multi(db, qs)
+                for i, q in enumerate(qs):
+                    assert np.array_equal(got[i], orc.score_db(q, flat, off, sc.table(), -2, -1)), (name, opts, i, st)
+            db.close()
+    _reset_options(ctx)
+    ctx.set_option("autotune", 1)
 
 
 def test_multipass_through_the_work_queue(swg, ctx, orc):
