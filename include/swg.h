@@ -154,7 +154,8 @@ int swg_abi_version(void);
  * queries on the f16 cells runs two queries per lane | 0: two sequences per lane as a single query does), "side_readout" (1 default:
  * top-K selection and read-out of a search run on their own stream, beside the fill of the search
  * queued next), "batch" (8 default: pairs one work-queue request claims where pairs are short -- at most
- * "batch_blocks" (16 default) 4-row token blocks long; 0 / 1: every request claims one pair). */
+ * "batch_blocks" 4-row token blocks long (0 default: about 40 us of work at the launch's geometry: 30 blocks at 2
+ * columns per lane, 5 at 32); batch 0 / 1: every request claims one pair). */
 int swg_set_option(swg_ctx *ctx, const char *key, long value);
 
 /* Replaces scoring_t for the path (reference src/alignment_scoring.h:21-37):

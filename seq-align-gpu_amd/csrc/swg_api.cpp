@@ -302,7 +302,7 @@ extern "C" int swg_set_option(swg_ctx *ctx, const char *key, long value)
         if (value < 0 || value > 8) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "batch must be 0..8 (pairs one queue request claims; 0 and 1: one)");
         ctx->opt_batch = value;
     } else if (!strcmp(key, "batch_blocks")) {
-        if (value < 1) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "batch_blocks must be >= 1 (token blocks)");
+        if (value < 0) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "batch_blocks must be >= 0 (token blocks; 0: from the geometry)");
         ctx->opt_batch_blocks = value;
     } else if (!strcmp(key, "work_queue")) {
         ctx->opt_dynamic = value != 0;
@@ -841,16 +841,27 @@ static int prepare_diag(swg_ctx *ctx, swg_db *db, const SwgDiagWork &wk)
 }
 
 // The queue's zones for one launch over pairs [q->q_begin, q->q_end) (see the kernel's event code): the pairs of at most
-// opt_batch_blocks token blocks -- lengths do not increase along the range -- are claimed opt_batch at a time, except
+// N token blocks (see below) -- lengths do not increase along the range -- are claimed opt_batch at a time, except
 // the last two per lane group, which go out one by one again so that the lane groups still end together (a claim of
 // B pairs is B times the granularity of the hand-out).  Whole batches only; shard c's first U1 requests are single.
-static void dyn_batch_zones(const swg_ctx *ctx, const SwgPairTokens &T, SwgDiagDynParams *q, uint64_t groups)
+static void dyn_batch_zones(const swg_ctx *ctx, const SwgPairTokens &T, SwgDiagDynParams *q, uint64_t groups, int K, int G, int form)
 {
     q->batch_u1 = q->batch_u2 = q->batch_B = 0u;
     const uint32_t B = (uint32_t)ctx->opt_batch;
     if (B <= 1u || q->list || q->q_end <= q->q_begin) return;
     const std::vector<uint32_t> &pre = T.pair_blocks_prefix;
-    const uint32_t N = (uint32_t)std::min<long>(ctx->opt_batch_blocks, 1l << 30);
+    // "Short" is a time, not a length: a request costs ~2.2 us, so batches pay where a whole pair takes a few tens of
+    // microseconds -- and a claim of B pairs is B pair-times taken out of the balance at the end of the launch.  A 4-row
+    // block costs 4 x (instructions per row) x 4.06 cycles of its SIMD, shared with the other wavefronts on it: 1.3 us
+    // at K = 2, 3 us at K = 8, 7 us at K = 32 (three wavefronts).  Pairs of at most 40 us count as short: 30 blocks at
+    // K = 2, 13 at K = 8, 5 at K = 32.  (Measured, round 4: a fixed 32 blocks cost config 3 -- K = 32 -- 6 %: 2 300
+    // claims of eight 30-block pairs, 1.5 ms of work each, ended after everybody else.)  Option batch_blocks > 0 overrides.
+    uint32_t N = (uint32_t)std::min<long>(ctx->opt_batch_blocks, 1l << 30);
+    if (ctx->opt_batch_blocks <= 0) {
+        const double waves_per_simd = std::min(4.0, std::max(1.0, (double)groups * G / 64.0 / (4.0 * ctx->n_cu)));
+        const double block_us = 4.0 * ((form == 2 ? 8.5 : 10.0) * K + 30.0) * 4.06 * waves_per_simd / 2.4e3;
+        N = (uint32_t)std::max(2.0, 40.0 / block_us);
+    }
     uint32_t lo = q->q_begin, hi = q->q_end; // first pair with at most N blocks
     while (lo < hi) {
         const uint32_t mid = lo + (hi - lo) / 2u;
@@ -996,7 +1007,7 @@ static int launch_diag(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, in
                         const int variant = pass + 1 == pl.npass && pl.npass > 1 && pl.last_variant >= 0 ? pl.last_variant : pl.variant;
                         const int wgs_c = diag_class_workgroups(ctx, db, wk, c);
                         // (with long_helps the long class's kernel reads the bulk's counters too, as single pairs: no zones then)
-                        if (!(ctx->opt_long_helps && wk.n_classes == 2)) dyn_batch_zones(ctx, T, &q, (uint64_t)wgs_c * pl.W * (64 / pl.G));
+                        if (!(ctx->opt_long_helps && wk.n_classes == 2)) dyn_batch_zones(ctx, T, &q, (uint64_t)wgs_c * pl.W * (64 / pl.G), swg_diag_variant_info(variant).K, pl.G, pform);
                         HIP_TRY(ctx, swg_launch_diag_dyn(variant, edges, pform, pl.W, wgs_c, q, qs));
                         ++launches;
                         if (split && part == 1) ++f16_launches;
@@ -2772,7 +2783,7 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
             }
             q.turn_levels = wk.n_classes == 2 ? 3u : 4u;
             q.simd_ranks = B.d_cnt + Qb_max * 2 * cnt_class + (size_t)c * SWG_DYN_SIMD_SLOTS;
-            dyn_batch_zones(ctx, T, &q, (uint64_t)wgs[c] * pl.W * (64 / pl.G));
+            dyn_batch_zones(ctx, T, &q, (uint64_t)wgs[c] * pl.W * (64 / pl.G), pl.K, pl.G, form);
             HIP_TRY(ctx, swg_launch_diag_dyn(pl.variant, false, form, pl.W, wgs[c], q, c == 1 ? ctx->stream2 : s, (int)Qb));
         }
         if (wk.n_classes == 2) {

@@ -237,7 +237,7 @@ struct swg_ctx {
     // options
     long opt_force_bits = 0, opt_cols = 0, opt_max_waves = 0, opt_workgroups = 0, opt_engine = 0, opt_group = 0, opt_long_split = 0, opt_autotune = 1, opt_dynamic = 1, opt_prio_share = 150, opt_long_helps = 0, opt_wide = 1, opt_side_readout = 1, opt_f16 = 1, opt_qq = 1, opt_last_pass = 1;
     long opt_wave_budget = 0, opt_q32_waves = 0;
-    long opt_batch = 8, opt_batch_blocks = 16; // work queue: pairs one request claims where pairs are at most that many token blocks long
+    long opt_batch = 8, opt_batch_blocks = 0; // work queue: pairs one request claims where pairs are short (blocks; 0: about 40 us of work, from the geometry)
     uint32_t opt_seg_blocks = SWG_DYN_SEG_BLOCKS; // token blocks per launch of the multi-pass fill (option "segment_blocks": tests)
     // device state
     int8_t *d_sub = nullptr;

@@ -59,7 +59,7 @@ def main(budget=300.0, seed=1):
         for k in ("work_queue", "wide16", "autotune", "side_readout", "f16", "last_pass"):
             ctx.set_option(k, 1)
         ctx.set_option("long_helps", 0)
-        ctx.set_option("batch", 8); ctx.set_option("batch_blocks", 16)
+        ctx.set_option("batch", 8); ctx.set_option("batch_blocks", 0)
         opts = {}
         r = rng.random()
         if r < 0.25:

@@ -57,7 +57,7 @@ def main(budget=300.0, seed=1):
             ctx.set_option(k_, 0)
         for k_ in ("work_queue", "wide16", "autotune", "side_readout", "f16", "qq", "last_pass"):
             ctx.set_option(k_, 1)
-        ctx.set_option("batch", 8); ctx.set_option("batch_blocks", 16)
+        ctx.set_option("batch", 8); ctx.set_option("batch_blocks", 0)
         opts = {}
         if rng.random() < 0.25: opts["batch"] = int(rng.choice([0, 3, 8]))
         if rng.random() < 0.25: opts["batch_blocks"] = int(rng.choice([1, 64, 100000]))

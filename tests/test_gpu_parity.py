@@ -22,7 +22,7 @@ DEFAULT_OFF = ("long_helps",)
 
 def _reset_options(ctx):
     ctx.set_option("batch", 8)
-    ctx.set_option("batch_blocks", 16)
+    ctx.set_option("batch_blocks", 0)
     for k in OPTIONS:
         ctx.set_option(k, 0)
     for k in DEFAULT_ON:
