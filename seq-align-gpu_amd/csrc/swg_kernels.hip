@@ -854,7 +854,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_kernel(const SwgDiagParams
 // LDS record of a lane group: [0] value of the wavefront's block counter at which
 // the current pair has no more tokens to load (NONE: no pair and none to come),
 // [1] flags, [2] ids pushed, [3], [4], [6], [8..16] the group's batch of short pairs (SWG_DYN_MAX_BATCH),
-// [32..63] ring of pair ids, [64..127] ring of score pairs.
+// [32..63] ring of pair ids ([64..127] held a ring of score pairs until round 4: the scores travel in registers now).
 #ifndef SWG_DYN_FENCE_ABOVE
 #define SWG_DYN_FENCE_ABOVE 16 // fence the profile prefetch for K above this
 #endif
@@ -1509,7 +1509,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     {
         uint32_t *st = record();
         if (g < 4) st[g] = 0u; // every group is due at block 0
-        for (uint32_t i = (uint32_t)g; i < 2u * SWG_DYN_RING; i += (uint32_t)G) st[SWG_DYN_MAXES + i] = 0u;
     }
     __syncthreads();
 
@@ -1518,6 +1517,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
     uint32_t tok = 0u;
     int m_out = 0, b_out = 0, d_out = 0; // right edge of the lane's strip: (M, B), or (L, B, D) in the exact form
     int go_v = (int)p.go, ge_v = (int)p.ge;
+    int bc = 0; // the current sequence's best on its way along its last row (see swg_diag_dyn_kernel)
     uint32_t nlast = 0u;
     // v_perm selector of the leader: residue byte of X (.. 00) or Y (.. 01), zero, flags byte, zero.  It
     // belongs to the sequence whose tokens are being LOADED; the blocks in flight keep the selector they
@@ -1690,17 +1690,22 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag32q_kernel(const SwgDiagQ32
             if (special) {
                 go_v = (int)p.go;
                 ge_v = (int)p.ge;
-                if (tok & SWG_TOK_LAST) {
-                    uint32_t *st = record();
-                    const uint32_t at = nlast & (SWG_DYN_RING - 1u);
-                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + at, (uint32_t)cells.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (tail) {
-                        const uint32_t seq = st[SWG_DYN_RING + at];
-                        const uint32_t sc = __hip_atomic_exchange(st + SWG_DYN_MAXES + at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (seq < p.seq_limit) {
-                            if (EDGES) atomicMax(p.scores + seq, (int)sc); // one pass of several
-                            else p.scores[seq] = (int)sc;
-                        }
+                // the sequence's score travels along its last row from lane to lane (see swg_diag_dyn_kernel)
+                {
+                    uint32_t cin;
+                    if (G16) {
+                        cin = dpp_zero<DPP_ROW_SHR1>((uint32_t)bc);
+                    } else {
+                        const uint32_t u5 = dpp_zero<DPP_WAVE_SHR1>((uint32_t)bc);
+                        cin = (GW == 32 && leader) ? 0u : u5; // lane 32 starts a group too
+                    }
+                    bc = imax((int)cin, cells.best);
+                }
+                if (tail && (tok & SWG_TOK_LAST) != 0u) {
+                    const uint32_t seq = record()[SWG_DYN_RING + (nlast & (SWG_DYN_RING - 1u))];
+                    if (seq < p.seq_limit) {
+                        if (EDGES) atomicMax(p.scores + seq, bc); // one pass of several
+                        else p.scores[seq] = bc;
                     }
                     ++nlast;
                 }
@@ -1827,7 +1832,6 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
     {
         uint32_t *st = record();
         if (g < 4) st[g] = 0u; // every group is due at block 0
-        for (uint32_t i = (uint32_t)g; i < 2u * SWG_DYN_RING; i += (uint32_t)G) st[SWG_DYN_MAXES + i] = 0u;
     }
     __syncthreads();
     const uint32_t n_items = p.q_end - p.q_begin;
@@ -1838,7 +1842,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
     uint32_t em_rot[2] = {Z, Z}, eb_rot[2] = {Z, Z}; // (written only by the DPP moves: the leader keeps score 0, see swg_diag_dyn_kernel)
     uint32_t zero_v = Z;
     asm volatile("" : "+v"(zero_v));
-    uint32_t wipe_next = 0u; // (see swg_diag_dyn_kernel)
+    uint32_t bc = Z; // the current sequence's bests on their way along its last row (see swg_diag_dyn_kernel)
     uint32_t go_v = p.go, ge_v = p.ge;
     uint32_t nlast = 0u;
     // v_perm selector of the leader: residue byte of X (.. 00) or Y (.. 01), zero, flags byte, zero; the blocks in
@@ -1958,11 +1962,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
             if (special) {
                 uint32_t fm = 0u - ((tok >> 16) & 1u);
                 asm volatile("" : "+v"(fm)); // (keeps this a branch)
-                const uint32_t fi = fm & wipe_next;
-                if (__builtin_amdgcn_ballot_w64(fi != 0u) != 0ull) {
-                    cells.wipe(fi);
-                    wipe_next &= ~fi;
-                }
+                // (no wipe test: a batch runs on these cells only when no query of it can score 4096, let alone 32768)
                 cells.best = (cells.best & ~fm) | (Z & fm);
                 go_v = (go_v & ~fm) | (SWG_F16_BIG & fm);
                 ge_v = (ge_v & ~fm) | (SWG_F16_BIG & fm);
@@ -1971,20 +1971,22 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_qq_kernel(const SwgDiagQQP
             if (special) {
                 go_v = p.go;
                 ge_v = p.ge;
-                if (tok & SWG_TOK_LAST) {
-                    uint32_t *st = record();
-                    const uint32_t at = nlast & (SWG_DYN_RING - 1u);
-                    wipe_next = cells.best_is_huge();
-                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at, f16_key(cells.best & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_max(st + SWG_DYN_MAXES + 2u * at + 1u, f16_key(cells.best >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (tail) {
-                        const uint32_t seq = st[SWG_DYN_RING + at];
-                        const uint32_t sa = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t sb = __hip_atomic_exchange(st + SWG_DYN_MAXES + 2u * at + 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (seq < p.seq_limit) {
-                            scores_a[seq] = f16_score(sa);
-                            if (have_b) scores_b[seq] = f16_score(sb);
-                        }
+                // the sequence's two scores (one per query of the pair) travel along its last row: see swg_diag_dyn_kernel
+                {
+                    uint32_t cin;
+                    if (G16) {
+                        cin = dpp_keep<DPP_ROW_SHR1>(Z, bc);
+                    } else {
+                        const uint32_t u3 = dpp_keep<DPP_WAVE_SHR1>(Z, bc);
+                        cin = (GW == 32 && leader) ? Z : u3;
+                    }
+                    bc = pk_max3_f16(cin, cells.best, cells.best);
+                }
+                if (tail && (tok & SWG_TOK_LAST) != 0u) {
+                    const uint32_t seq = record()[SWG_DYN_RING + (nlast & (SWG_DYN_RING - 1u))];
+                    if (seq < p.seq_limit) {
+                        scores_a[seq] = f16_score(f16_key(bc & 0xFFFFu));
+                        if (have_b) scores_b[seq] = f16_score(f16_key(bc >> 16));
                     }
                     ++nlast;
                 }
