@@ -181,6 +181,7 @@ _sig("swg_synth_free", None, [_vp])
 # test hook, declared in csrc/swg_host_internal.h (not part of the public ABI)
 _sig("swg_debug_fail_alloc", None, [C.c_int])
 _sig("swg_debug_sort_count", C.c_ulong, [])
+_sig("swg_debug_engine", C.c_int, [_vp, C.c_size_t, C.c_int, C.c_int, _vp])
 _sig("swg_debug_plan", C.c_int, [_vp, C.c_size_t, C.c_int, _vp])
 _sig("swg_debug_split", C.c_int, [_vp, C.c_size_t, C.c_uint64, _vp])
 _sig("swg_debug_pair_tokens", C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)])
@@ -410,6 +411,13 @@ class Database:
         keys = ("classes", "K", "G", "W", "passes", "workgroups", "long_pairs", "long_K", "long_G", "long_W", "long_workgroups", "est_us",
                 "last_pass_cols")
         return dict(zip(keys, (int(v) for v in out)))
+
+    def debug_engine(self, lq, n_cu=256, form=2):
+        """Test hook: the cost model's estimates of both engines for this database and a query of lq residues (no device
+        needed) -> dict(diag_us, systolic_us, systolic_K, systolic: the model picks the systolic engine)."""
+        out = np.zeros(4, dtype=np.int32)
+        _check(lib.swg_debug_engine(self.handle, lq, n_cu, form, out.ctypes.data_as(_vp)))
+        return {"diag_us": int(out[0]), "systolic_us": int(out[1]), "systolic_K": int(out[2]), "systolic": bool(out[3])}
 
     def debug_split(self, lq, qbound):
         """Test hook: the both-forms cut (a query of lq columns that can score qbound at best) -> rows, first pair of the

@@ -1826,6 +1826,27 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             use_diag = swg_plan_diag_work(db, lq, ctx->n_cu, ctx->opt_cols, ctx->opt_group, ctx->opt_max_waves,
                                           ctx->opt_long_split, ctx->opt_workgroups == 0,
                                           ctx->opt_dynamic != 0 && db->ptok.ok, &wk, 1.0, plan_form) > 0;
+        // The cost model's word on the ENGINE (round 4; until then only the autotuner could pick the systolic one, and it
+        // is off for databases beyond 4 M sequences and wherever the caller turned it off): a database of short sequences
+        // of near-equal length -- peptides -- is what the systolic engine is good at (no reset rows, no flags, nothing per
+        // pair: 2 M peptides of 20-40 residues, lq 128: 6 570 GCUPS against the lane groups' 4 840, lq 30: 4 820 against
+        // 1 930), and the two estimates tell: the lane groups' from the planner, the systolic one from the bin table.
+        // It has to win by 15 % (both models are good to about 10 %).
+        if (use_diag && !tuned_systolic && free_geometry && ctx->opt_engine == 0 && ctx->opt_f16 != 2 && !wide && !db->tokens_only && it == mdb->tuned.end() &&
+            wk.plan[0].est_ms > 0.0) {
+            int sys_K = 0;
+            const double sys_ms = swg_systolic_estimate_ms(db, lq, ctx->n_cu, &sys_K);
+            if (sys_K > 0 && sys_ms < SWG_SYSTOLIC_MARGIN * wk.plan[0].est_ms * swg_diag_short_pair_factor(db, wk.plan[0], plan_form)) {
+                const long keep = ctx->opt_cols;
+                ctx->opt_cols = sys_K;
+                const int rs = make_plan(ctx, 16, n_bins, &main_pl);
+                ctx->opt_cols = keep;
+                if (rs == SWG_OK) {
+                    use_diag = false;
+                    tuned_systolic = true;
+                }
+            }
+        }
         if (!use_diag && !tuned_systolic && ctx->opt_engine == 2)
             return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no diagonal-engine geometry for these options");
         if (use_diag && ctx->opt_workgroups > 0) {

@@ -482,6 +482,77 @@ extern "C" int swg_debug_split(swg_db *db, size_t lq, uint64_t qbound, uint64_t 
     return SWG_OK;
 }
 
+// What the systolic engine (swg_fill_kernel: lane l owns sequences 2l, 2l+1 of a 128-sequence bin, W wavefronts of a
+// workgroup chained over the query, int16 cells) would need for this database, by the host's bin table: a bin costs its
+// LONGEST member's rows (rounded to 4-row blocks) on every one of the W wavefronts, 10 K + 12 instructions per row, plus
+// ~5 000 cycles per bin and wavefront for taking it off the work counter; and the search cannot end before the longest
+// bin's chain has, at the rate of a wavefront that shares its SIMD.  Calibrated on 2 M peptides (round 4,
+// profiles/r04_peptides_systolic.txt: lq 128 K 32 x 4 wavefronts 1.15 ms measured / 1.21 estimated, lq 30 K 16 x 2 0.37 /
+// 0.33) and on config 2, where the 5 000-row bin's chain is the whole search (11.8 ms measured, 11 estimated).
+// Returns the estimate in ms and the columns per wavefront of the best single-pass instantiation (0: none).
+double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best_K)
+{
+    *best_K = 0;
+    if (db->n_bins == 0 || db->bin_nblk.size() != db->n_bins) return 1e300;
+    uint64_t blocks = 0;
+    for (uint32_t b : db->bin_nblk) blocks += b;
+    const double rows = 4.0 * (double)blocks, longest = 4.0 * (double)db->max_nblk;
+    double best = 1e300;
+    for (int v = 0; v < swg_num_variants(16); ++v) {
+        const SwgKernelInfo info = swg_variant_info(16, v);
+        const int W = (int)((lq + (size_t)info.K - 1) / (size_t)info.K);
+        if (W > info.max_waves) continue; // (several passes: never the better engine)
+        if (info.K > 32) continue;         // (the 48-column instantiation runs at two wavefronts per SIMD: measured 45 % over its count)
+        const size_t lds = info.lds_per_wave * (size_t)W + info.lds_fixed;
+        const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)));
+        const double waves_per_simd = std::max(1.0, per_cu * W / 4.0);
+        const double instr = 10.0 * info.K + 12.0;
+        const double thr = (rows * W * instr * 4.06 + (double)db->n_bins * W * 5000.0) / (4.0 * n_cu);
+        const double chain = longest * instr * 4.06 * std::min(4.0, waves_per_simd);
+        const double ms = std::max(thr, chain) / 2.4e6;
+        if (ms < best) best = ms, *best_K = info.K;
+    }
+    return best;
+}
+
+// The planner's estimate for the lane groups was fitted on BASELINE's length distribution (pairs of ~380 rows), where
+// about 40 % of a wavefront's steps find one of its 64 lanes on a flagged row (a pair's two reset rows and its last row)
+// and take the rare branch; its cost there is inside the fitted intercept.  A database of SHORT pairs takes that branch
+// on nearly every step: 19 instructions more per wavefront-row than the fit knows, scaled by how much more often
+// (peptides: K = 8, 98 fitted instructions per row, measured 1.56 ms where the unadjusted estimate says 1.41).  Used where
+// the two engines are compared, not in the ranking of geometries (the term is the same for all of them).
+double swg_diag_short_pair_factor(const swg_db *db, const SwgDiagPlan &pl, int form)
+{
+    const uint64_t n_pairs = swg_db_pair_count(db);
+    if (n_pairs == 0) return 1.0;
+    uint64_t longest = 0;
+    const double L = std::max(4.0, (double)swg_db_pair_rows(db, 0, n_pairs, &longest) / (double)n_pairs);
+    auto p_flag = [](double rows) { return 1.0 - std::pow(std::max(0.0, 1.0 - 3.0 / rows), 64.0); };
+    const double extra = 19.0 * std::max(0.0, p_flag(L) - p_flag(380.0));
+    return 1.0 + extra / instr_per_row(pl.K, pl.G, form);
+}
+
+// test hook: both engines' estimates for a database and a query length (cells: 0 int16, 2 packed f16), without a device:
+// out[0] lane groups (us), out[1] systolic (us), out[2] its columns per wavefront, out[3] 1 = the model picks the systolic engine
+extern "C" int swg_debug_engine(const swg_db *db, size_t lq, int n_cu, int form, int32_t *out)
+{
+    if (!db || !out || lq == 0 || n_cu <= 0) return SWG_ERR_ARG;
+    SwgDiagWork wk;
+    try {
+        if (swg_plan_diag_work(db, lq, n_cu, 0, 0, 0, 0, true, true, &wk, 1.0, form) <= 0) return SWG_ERR_ARG;
+    } catch (const std::exception &) {
+        return SWG_ERR_NOMEM;
+    }
+    int K = 0;
+    const double sys = swg_systolic_estimate_ms(db, lq, n_cu, &K);
+    const double diag = wk.plan[0].est_ms * swg_diag_short_pair_factor(db, wk.plan[0], form);
+    out[0] = (int32_t)(diag * 1e3);
+    out[1] = K > 0 ? (int32_t)std::min(sys * 1e3, 2.0e9) : -1;
+    out[2] = K;
+    out[3] = K > 0 && sys < SWG_SYSTOLIC_MARGIN * diag ? 1 : 0;
+    return SWG_OK;
+}
+
 // Test hook (not part of the public ABI, declared in swg_host_internal.h): the cost model's first choice
 // for a packed database and a query length on a device of n_cu compute units, without a device.
 // out[0..12] = classes, K, G, W, passes, workgroups, long pairs, long K, long G, long W, long workgroups,

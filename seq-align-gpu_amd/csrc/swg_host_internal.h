@@ -267,6 +267,12 @@ void swg_db_release_device(swg_db *db);
 // test hook: the next visit of the named site throws std::bad_alloc (swg_api.cpp); 0 disarms
 extern "C" void swg_debug_fail_alloc(int site);
 extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *out);
+// the systolic engine's estimate from the host's bin table (swg_diag_host.cpp); it is picked over the lane groups when it
+// wins by this margin (both models are good to about 10 %)
+#define SWG_SYSTOLIC_MARGIN 0.85
+double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best_K);
+double swg_diag_short_pair_factor(const swg_db *db, const SwgDiagPlan &pl, int form); // lane groups on short pairs: what the fitted estimate misses
+extern "C" int swg_debug_engine(const swg_db *db, size_t lq, int n_cu, int form, int32_t *out);
 extern "C" int swg_debug_split(swg_db *db, size_t lq, uint64_t qbound, uint64_t *out);
 // decisions swg_search_begin makes on top of the planner's geometry (host only: swg_diag_host.cpp)
 bool swg_plan_last_pass(const SwgDiagPlan &pl, size_t lq, int *variant, int *K);

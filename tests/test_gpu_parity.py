@@ -827,10 +827,12 @@ def test_pairs_claimed_by_the_batch(swg, ctx, orc):
                     continue                                                     # (several passes need a query beyond G * K columns)
                 _reset_options(ctx)
                 ctx.set_option("autotune", 0)
+                ctx.set_option("engine", 2)        # (left alone the cost model gives peptides to the systolic engine)
                 for k, v in opts.items():
                     ctx.set_option(k, v)
                 db = swg.Database(flat, off).upload(ctx)
                 got, hits, st = ctx.search(db, k=5)
+                assert st["engine"] == 2 and st["work_queue"] == 1
                 assert np.array_equal(got, want), (name, lq, opts, st)
                 assert hits == orc.topk(want, 5)
                 db.close()
@@ -846,6 +848,52 @@ def test_pairs_claimed_by_the_batch(swg, ctx, orc):
                 for i, q in enumerate(qs):
                     assert np.array_equal(got[i], orc.score_db(q, flat, off, sc.table(), -2, -1)), (name, opts, i, st)
             db.close()
+    _reset_options(ctx)
+    ctx.set_option("autotune", 1)
+
+
+def test_cost_model_gives_peptides_to_the_systolic_engine(swg, ctx, orc):
+    """Round 4: a database of short sequences of near-equal length is what the systolic engine is good at (no reset rows,
+    no flags, nothing per pair), and the cost model -- not only the autotuner -- says so: with autotune off, 300 000
+    peptides of 20-40 residues run on engine 1 for short queries and on the lane groups for a long one, BASELINE's length
+    distribution stays on the lane groups, and the scores are the oracle's either way.  The systolic fill is at least a
+    quarter faster than the lane groups' on the same resident database."""
+    sc = swg.load_scoring("BLOSUM62")
+    ctx.set_scoring(sc, -2, -1)
+    flat, off = swg.synth_db(0xBEEF, 300000, median=29.0, sigma_ln=0.25, min_len=20, max_len=40)
+    lens = np.diff(off.astype(np.int64))
+    sample = np.linspace(0, len(lens) - 1, 6000).astype(np.int64)
+    s_off = np.zeros(len(sample) + 1, dtype=np.uint64)
+    s_off[1:] = np.cumsum(lens[sample])
+    s_flat = np.concatenate([flat[int(off[i]):int(off[i + 1])] for i in sample])
+    _reset_options(ctx)
+    ctx.set_option("autotune", 0)
+    db = swg.Database(flat, off).upload(ctx)
+    for lq, engine in ((30, 1), (128, 1), (600, 2)):
+        q = swg.synth_query(40 + lq, lq)
+        ctx.set_query(q)
+        want = orc.score_db(q, s_flat, s_off, sc.table(), -2, -1)
+        ctx.set_option("engine", 0)
+        got, hits, st = ctx.search(db, k=20)
+        assert st["engine"] == engine, (lq, st)
+        assert np.array_equal(got[sample], want), (lq, st)
+        order = np.lexsort((np.arange(len(got)), -got.astype(np.int64)))[:20]
+        assert hits == [(int(got[i]), int(i)) for i in order]
+        if engine == 1:
+            fills = {}
+            for e in (1, 2):
+                ctx.set_option("engine", e)
+                other, _, st2 = ctx.search(db)
+                assert st2["engine"] == e and np.array_equal(other, got), (lq, e)
+                fills[e] = min(ctx.search(db, want_scores=False)[2]["fill_ms"] for _ in range(3))
+            assert fills[1] < 0.8 * fills[2], (lq, fills)
+    db.close()
+    flat, off = swg.synth_db(0x5EED0002, 20000)
+    db = swg.Database(flat, off).upload(ctx)
+    ctx.set_option("engine", 0)
+    ctx.set_query(swg.synth_query(1, 128))
+    assert ctx.search(db)[2]["engine"] == 2
+    db.close()
     _reset_options(ctx)
     ctx.set_option("autotune", 1)
 
