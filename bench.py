@@ -504,8 +504,11 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     elif last["engine"] == 2:
         ops_per_cell, kname = 12.0, "swg_diag32_kernel"
     else:
-        ops_per_cell = 5.0 if last["path_bits"] == 16 else 12.0
-        kname = "swg_fill_kernel<CellsI%d>" % last["path_bits"]
+        sys_f16 = last["path_bits"] == 16 and int(last["cell_form"]) == 2       # the systolic engine on packed-f16 cells
+        ops_per_cell = 4.25 if sys_f16 else 5.0 if last["path_bits"] == 16 else 12.0
+        kname = "swg_fill_kernel<CellsSF16<%d>>" % last["cols_per_wave"] if sys_f16 else "swg_fill_kernel<CellsI%d<%d>>" % (last["path_bits"], last["cols_per_wave"])
+        if sys_f16:
+            form = 2
     if q16 and form not in (4, 5) and int(last["last_pass_cols"]) > 0 and int(last["passes"]) > 1:
         # the last pass of a long query runs an instantiation with fewer columns per lane: kernel_ms is the mean over
         # all the launches of one search's fill, i.e. rocprofv3's two per-kernel averages weighted by their calls

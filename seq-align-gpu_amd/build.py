@@ -73,7 +73,7 @@ def _headers():
 
 
 OBJDUMP = os.path.join(ROCM, "lib", "llvm", "bin", "llvm-objdump")
-FAMILIES = ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_diag32q_kernel", "swg_diag_qq_kernel")
+FAMILIES = ("swg_diag_dyn_kernel", "swg_diag_kernel", "swg_fill_kernelI8CellsI16", "swg_fill_kernelI9CellsSF16", "swg_diag32q_kernel", "swg_diag_qq_kernel")
 ISA_STAMP = os.path.join(OBJ, "isa_checked")
 
 

@@ -526,6 +526,7 @@ static int ensure_bins(swg_ctx *ctx, swg_db *db)
 struct Plan {
     int bits, variant, K, W, npass, workgroups;
     SwgKernelInfo info;
+    int f16; // systolic int16 plan on the packed-f16 cells (one pass, no score of the search can reach 4096)
 };
 
 static int make_plan(swg_ctx *ctx, int bits, uint32_t n_items, Plan *pl)
@@ -597,7 +598,7 @@ static int ensure_profile_cols(swg_ctx *ctx, int which, uint32_t ncols, int elem
 static int ensure_profile(swg_ctx *ctx, const Plan &pl)
 {
     return ensure_profile_cols(ctx, pl.bits == 16 ? 0 : 1, (uint32_t)(pl.npass * pl.W * pl.K), pl.info.elem_size,
-                               ((uint64_t)pl.K << 20) ^ ((uint64_t)pl.W << 12) ^ (uint64_t)pl.npass);
+                               ((uint64_t)pl.K << 20) ^ ((uint64_t)pl.W << 12) ^ (uint64_t)pl.npass, 1, 1, 4, 0, pl.bits == 16 && pl.f16);
 }
 
 // Stream layout of the diagonal engine for this database at this stream count,
@@ -1100,7 +1101,10 @@ static int launch_systolic(swg_ctx *ctx, const swg_db *db, const Plan &pl, int g
     p.queue = db->d_counters + 0;
     p.n_items = pl.bits == 16 ? db->n_bins : db->n_bins * 2;
     p.npass = (uint32_t)pl.npass;
-    if (pl.bits == 16) {
+    if (pl.bits == 16 && pl.f16) {
+        p.go = (int32_t)f16x2_of(-go);
+        p.ge = (int32_t)f16x2_of(-ge);
+    } else if (pl.bits == 16) {
         const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
         p.go = (int32_t)(g | (g << 16));
         p.ge = (int32_t)(e | (e << 16));
@@ -1110,7 +1114,7 @@ static int launch_systolic(swg_ctx *ctx, const swg_db *db, const Plan &pl, int g
     }
     p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * pl.info.nb;
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[1], s));
-    HIP_TRY(ctx, swg_launch_fill(pl.bits, pl.variant, pl.W, pl.workgroups, p, s));
+    HIP_TRY(ctx, swg_launch_fill(pl.bits, pl.variant, pl.W, pl.workgroups, p, s, pl.bits == 16 && pl.f16));
     HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
     return SWG_OK;
 }
@@ -1835,7 +1839,8 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         if (use_diag && !tuned_systolic && free_geometry && ctx->opt_engine == 0 && ctx->opt_f16 != 2 && !wide && !db->tokens_only && it == mdb->tuned.end() &&
             wk.plan[0].est_ms > 0.0) {
             int sys_K = 0;
-            const double sys_ms = swg_systolic_estimate_ms(db, lq, ctx->n_cu, &sys_K);
+            const bool sys_f16 = ctx->opt_f16 != 0 && -go <= 2048 && -ge <= 2048 && score_bound < 4096ull;
+            const double sys_ms = swg_systolic_estimate_ms(db, lq, ctx->n_cu, &sys_K, sys_f16);
             if (sys_K > 0 && sys_ms < SWG_SYSTOLIC_MARGIN * wk.plan[0].est_ms * swg_diag_short_pair_factor(db, wk.plan[0], plan_form)) {
                 const long keep = ctx->opt_cols;
                 ctx->opt_cols = sys_K;
@@ -1862,6 +1867,11 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         else
             wide = false;
     }
+    // The systolic engine on packed-f16 cells (round 4: 8.5 instead of 10 instructions per column pair) where NO score of
+    // this search can reach their ceiling -- the engine has no flag-and-re-run route, and the databases the cost model
+    // gives it are the ones whose longest sequence is short (372 residues x BLOSUM62's 11 < 4096).
+    if (bits == 16 && !use_diag && main_pl.npass == 1 && ctx->opt_f16 != 0 && -go <= 2048 && -ge <= 2048 && score_bound < 4096ull)
+        main_pl.f16 = 1;
     // int32 work (forced / unusual gap scores / re-score of saturated sequences) also runs on
     // the diagonal engine unless the systolic one is asked for
     const bool use_diag32 = ctx->opt_engine != 1;
@@ -2053,7 +2063,10 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
         p.list_count = nullptr;
         p.n_items = bits == 16 ? n_bins : n_bins * 2;
         p.npass = (uint32_t)main_pl.npass;
-        if (bits == 16) {
+        if (bits == 16 && main_pl.f16) {
+            p.go = (int32_t)f16x2_of(-go);
+            p.ge = (int32_t)f16x2_of(-ge);
+        } else if (bits == 16) {
             const uint32_t g = (uint32_t)(-go) & 0xFFFFu, e = (uint32_t)(-ge) & 0xFFFFu;
             p.go = (int32_t)(g | (g << 16));
             p.ge = (int32_t)(e | (e << 16));
@@ -2062,7 +2075,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
             p.ge = ge;
         }
         p.scratch_wg_dwords = (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 64 * main_pl.info.nb;
-        HIP_TRY(ctx, swg_launch_fill(bits, main_pl.variant, main_pl.W, main_pl.workgroups, p, s));
+        HIP_TRY(ctx, swg_launch_fill(bits, main_pl.variant, main_pl.W, main_pl.workgroups, p, s, bits == 16 && main_pl.f16 != 0));
     }
     if (!use_diag && !use_q32) HIP_TRY(ctx, hipEventRecord(ctx->cur->ev[2], s));
     int32_t level_ceiling = ceiling; // what the fill before the int32 level saturates at
@@ -2168,6 +2181,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
     S->npass32 = npass32;
     S->wk = wk;
     S->main_K = main_pl.K;
+    S->main_f16 = main_pl.f16 != 0;
     S->main_W = main_pl.W;
     S->main_npass = main_pl.npass;
     S->main_wgs = main_pl.workgroups;
@@ -2234,7 +2248,7 @@ static int search_end(swg_ctx *ctx, SwgSlot *S, int32_t *scores_out, swg_hit *to
     const double topk_dev_ms = ms;
     st.n_rescored = S->used_f16 ? h_counters[16] : h_counters[1];
     st.path_bits = bits;
-    st.cell_form = use_diag ? diag_class_form(ctx, db, dpl) : 0;
+    st.cell_form = use_diag ? diag_class_form(ctx, db, dpl) : S->main_f16 ? 2 : 0;
     if (use_diag && dpl.f16_from != 0u) {
         st.cell_form = dpl.wide ? 4 : 5;
         st.n_rescored = (uint64_t)h_counters[16] + h_counters[1]; // flagged by the f16 cells + saturated on the wide form

@@ -490,7 +490,7 @@ extern "C" int swg_debug_split(swg_db *db, size_t lq, uint64_t qbound, uint64_t 
 // profiles/r04_peptides_systolic.txt: lq 128 K 32 x 4 wavefronts 1.15 ms measured / 1.21 estimated, lq 30 K 16 x 2 0.37 /
 // 0.33) and on config 2, where the 5 000-row bin's chain is the whole search (11.8 ms measured, 11 estimated).
 // Returns the estimate in ms and the columns per wavefront of the best single-pass instantiation (0: none).
-double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best_K)
+double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best_K, bool f16)
 {
     *best_K = 0;
     if (db->n_bins == 0 || db->bin_nblk.size() != db->n_bins) return 1e300;
@@ -506,10 +506,12 @@ double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best
         const size_t lds = info.lds_per_wave * (size_t)W + info.lds_fixed;
         const int per_cu = std::max(1, std::min<int>(info.max_waves / W, (int)((160 * 1024) / lds)));
         const double waves_per_simd = std::max(1.0, per_cu * W / 4.0);
-        const double instr = 10.0 * info.K + 12.0;
+        const double instr = (f16 ? 8.5 : 10.0) * info.K + 12.0; // (packed-f16 cells where no score can reach 4096)
         const double thr = (rows * W * instr * 4.06 + (double)db->n_bins * W * 5000.0) / (4.0 * n_cu);
         const double chain = longest * instr * 4.06 * std::min(4.0, waves_per_simd);
-        const double ms = std::max(thr, chain) / 2.4e6;
+        // (the 24-column instantiation measures 30 % over its count -- peptides lq 128: 1.48 ms against 1.05 for 8 x 16 columns --
+        // and is only picked where that still wins)
+        const double ms = std::max(thr, chain) / 2.4e6 * (info.K == 24 ? 1.3 : 1.0);
         if (ms < best) best = ms, *best_K = info.K;
     }
     return best;
@@ -544,7 +546,9 @@ extern "C" int swg_debug_engine(const swg_db *db, size_t lq, int n_cu, int form,
         return SWG_ERR_NOMEM;
     }
     int K = 0;
-    const double sys = swg_systolic_estimate_ms(db, lq, n_cu, &K);
+    // (the hook has no scoring system: the f16 cells are assumed where BLOSUM62's largest entry, 11, keeps every score below 4096)
+    const bool f16 = form == 2 && (uint64_t)db->max_nblk * SWG_ROWS_PER_BLK * 11ull < 4096ull;
+    const double sys = swg_systolic_estimate_ms(db, lq, n_cu, &K, f16);
     const double diag = wk.plan[0].est_ms * swg_diag_short_pair_factor(db, wk.plan[0], form);
     out[0] = (int32_t)(diag * 1e3);
     out[1] = K > 0 ? (int32_t)std::min(sys * 1e3, 2.0e9) : -1;

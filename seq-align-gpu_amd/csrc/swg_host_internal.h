@@ -178,6 +178,7 @@ struct SwgSlot {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_done = nullptr; // polled from user space instead of a blocking stream sync
     uint64_t score_bound = ~0ull; // the largest score this search's query can reach against this database (launch_diag: f16_wipe)
+    bool main_f16 = false;        // the systolic fill ran on the packed-f16 cells
     bool side = false;            // this search's top-K and read-out were queued on the read-out stream (stream3)
     bool busy = false;
     const swg_db *db = nullptr;
@@ -270,7 +271,7 @@ extern "C" int swg_debug_plan(const swg_db *db, size_t lq, int n_cu, int32_t *ou
 // the systolic engine's estimate from the host's bin table (swg_diag_host.cpp); it is picked over the lane groups when it
 // wins by this margin (both models are good to about 10 %)
 #define SWG_SYSTOLIC_MARGIN 0.85
-double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best_K);
+double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best_K, bool f16 = false);
 double swg_diag_short_pair_factor(const swg_db *db, const SwgDiagPlan &pl, int form); // lane groups on short pairs: what the fitted estimate misses
 extern "C" int swg_debug_engine(const swg_db *db, size_t lq, int n_cu, int form, int32_t *out);
 extern "C" int swg_debug_split(swg_db *db, size_t lq, uint64_t qbound, uint64_t *out);

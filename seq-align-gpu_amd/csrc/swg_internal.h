@@ -185,7 +185,7 @@ struct SwgKernelInfo {
 int swg_num_variants(int bits);
 SwgKernelInfo swg_variant_info(int bits, int variant);
 hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups,
-                           const SwgFillParams &p, hipStream_t stream);
+                           const SwgFillParams &p, hipStream_t stream, bool f16 = false);
 
 // int32 diagonal engine: 64 lanes x SWG_DIAG32_K columns per pass, one sequence per wavefront.
 // Uses SwgFillParams: list/list_count/n_items = sequences (sorted ranks) to score, queue = work

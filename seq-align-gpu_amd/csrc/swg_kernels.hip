@@ -161,6 +161,9 @@ template <int K> struct CellsI16 {
     uint32_t M[K], G[K], A[K];
     uint32_t best, mdl;
 
+    DEVINL static edge_t zero_edge() { return make_uint2(0u, 0u); }                       // the column left of the query
+    DEVINL static int score(uint32_t b, int s) { return (int)((b >> (16 * s)) & 0xFFFFu); } // sequence s of the lane
+
     DEVINL void reset()
     {
 #pragma unroll
@@ -208,6 +211,76 @@ template <int K> struct CellsI16 {
 };
 
 // ---------------------------------------------------------------------------
+// packed-f16 cells for the systolic fill (round 4): the arithmetic of CellsDiag<K, 2> -- gfx950's three-operand maxima,
+// 8.5 instead of 10 instructions per column pair, a score v held as v - 2048, exact below 4096 -- for the engine that
+// short sequences run on.  Used only where no score of the search can reach 4096 (the host knows the bound: longest
+// sequence x largest table entry; 372 residues under BLOSUM62), so nothing is flagged and nothing re-run.
+// ---------------------------------------------------------------------------
+template <int K> struct CellsSF16 {
+    typedef uint2 edge_t;
+    static constexpr int SPL = 2;
+    static constexpr int ESZ = 2;
+    static constexpr int CHUNK = 32 * 4 * ESZ;
+    static constexpr int SLICE = (K / 4) * CHUNK;
+    static constexpr int OFF_SHIFT = 0;
+    static constexpr uint32_t Z = 0xE800E800u; // -2048.0 in both halves: score 0 (SWG_F16_ZERO)
+
+    uint32_t M[K], G[K], A[K];
+    uint32_t best, mdl, zero;
+
+    DEVINL static edge_t zero_edge() { return make_uint2(Z, Z); }
+    DEVINL static int score(uint32_t b, int s)
+    {
+        return (int)(float)__builtin_bit_cast(_Float16, (unsigned short)((b >> (16 * s)) & 0xFFFFu)) + 2048;
+    }
+
+    DEVINL void reset()
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) M[k] = G[k] = A[k] = Z;
+        best = Z;
+        mdl = Z;
+        zero = Z; // (the floor operand of the maxima lives in a register: a literal would be re-materialised per use)
+        asm volatile("" : "+v"(zero));
+    }
+
+    DEVINL edge_t row(const uint8_t *prof, const uint32_t (&off)[SPL], const edge_t ein, uint32_t go, uint32_t ge)
+    {
+        uint32_t md = mdl;
+        uint32_t gl = pk_sub_f16(ein.x, go); // unfloored: the maximum that uses it floors it
+        uint32_t bl = ein.y;
+#pragma unroll
+        for (int c = 0; c < K / 4; ++c) {
+            const uint2 wx = *reinterpret_cast<const uint2 *>(prof + off[0] + c * CHUNK);
+            const uint2 wy = *reinterpret_cast<const uint2 *>(prof + off[1] + c * CHUNK);
+            uint32_t s[4];
+            s[0] = __builtin_amdgcn_perm(wy.x, wx.x, 0x05040100u);
+            s[1] = __builtin_amdgcn_perm(wy.x, wx.x, 0x07060302u);
+            s[2] = __builtin_amdgcn_perm(wy.y, wx.y, 0x05040100u);
+            s[3] = __builtin_amdgcn_perm(wy.y, wx.y, 0x07060302u);
+            uint32_t mprev = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * c + u;
+                const uint32_t t = pk_add_f16(md, s[u]);
+                md = M[k];
+                const uint32_t a = pk_max3_f16(G[k], pk_sub_f16(A[k], ge), zero);
+                const uint32_t b = pk_max3_f16(gl, pk_sub_f16(bl, ge), zero);
+                const uint32_t m = pk_max3_f16(t, a, b);
+                M[k] = m;
+                A[k] = a;
+                gl = G[k] = pk_sub_f16(m, go);
+                bl = b;
+                if (u & 1) best = pk_max3_f16(best, mprev, m); // the running best takes two columns at a time
+                mprev = m;
+            }
+        }
+        mdl = ein.x;
+        return make_uint2(M[K - 1], bl);
+    }
+};
+
+// ---------------------------------------------------------------------------
 // int32 cells: one sequence per lane, the reference's recurrence term by term
 // ---------------------------------------------------------------------------
 template <int K> struct CellsI32 {
@@ -220,6 +293,8 @@ template <int K> struct CellsI32 {
 
     int U[K], A[K], D[K]; // previous row: U = max(H,B), A, D = max(H,A,B)
     int best, ddl;
+
+    DEVINL static edge_t zero_edge() { return make_uint4(0u, 0u, 0u, 0u); }
 
     DEVINL void reset()
     {
@@ -284,8 +359,6 @@ DEVINL uint4 load_edge_l2(const uint4 *p)
     const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
-DEVINL uint2 zero_edge(const uint2 *) { return make_uint2(0u, 0u); }
-DEVINL uint4 zero_edge(const uint4 *) { return make_uint4(0u, 0u, 0u, 0u); }
 
 // ---------------------------------------------------------------------------
 // The systolic fill
@@ -425,7 +498,7 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
                         // pass.  Same lane writes and reads: no barrier needed.
 #pragma unroll
                         for (int r = 0; r < SWG_ROWS_PER_BLK; ++r)
-                            ein_p[r * 64] = (pass == 0) ? zero_edge(sc) : load_edge_l2(sc + r * 64);
+                            ein_p[r * 64] = (pass == 0) ? Cells::zero_edge() : load_edge_l2(sc + r * 64);
                     }
 #pragma unroll
                     for (int r = 0; r < SWG_ROWS_PER_BLK; ++r) {
@@ -448,8 +521,8 @@ __global__ __launch_bounds__(MAXW * 64) void swg_fill_kernel(const SwgFillParams
                 if (blk == nb) {
                     // ---- end of this (item, pass): publish the maxima ------
                     if constexpr (SPL == 2) {
-                        atomicMax(p.scores + sid[0], (int)(cells.best & 0xFFFFu));
-                        atomicMax(p.scores + sid[1], (int)(cells.best >> 16));
+                        atomicMax(p.scores + sid[0], Cells::score(cells.best, 0));
+                        atomicMax(p.scores + sid[1], Cells::score(cells.best, 1));
                     } else {
                         if (sid[0] != 0xFFFFFFFFu) atomicMax(p.scores + sid[0], cells.best);
                     }
@@ -2618,6 +2691,7 @@ namespace {
 struct Variant {
     SwgKernelInfo info;
     void (*kernel)(const SwgFillParams);
+    void (*kernel_f16)(const SwgFillParams); // the same geometry on packed-f16 cells (int16 table only), or null
 };
 
 template <class Cells, int K, int MAXW, int BITS> Variant make_variant()
@@ -2631,16 +2705,23 @@ template <class Cells, int K, int MAXW, int BITS> Variant make_variant()
     v.info.lds_per_wave = Cells::SLICE + 2 * SWG_ROWS_PER_BLK * 64 * sizeof(typename Cells::edge_t);
     v.info.lds_fixed = 2 * SWG_ROWS_PER_BLK * 64 * sizeof(typename Cells::edge_t) + (SWG_ITEM_RING + 2) * 4;
     v.kernel = swg_fill_kernel<Cells, K, MAXW>;
+    v.kernel_f16 = nullptr;
+    return v;
+}
+template <int K, int MAXW> Variant make_variant16()
+{
+    Variant v = make_variant<CellsI16<K>, K, MAXW, 16>();
+    v.kernel_f16 = swg_fill_kernel<CellsSF16<K>, K, MAXW>;
     return v;
 }
 
 const Variant *variants16(int *n)
 {
     static const Variant v[] = {
-        make_variant<CellsI16<32>, 32, 12, 16>(),
-        make_variant<CellsI16<16>, 16, 16, 16>(),
-        make_variant<CellsI16<48>, 48, 8, 16>(),
-        make_variant<CellsI16<24>, 24, 16, 16>(),
+        make_variant16<32, 12>(),
+        make_variant16<16, 16>(),
+        make_variant16<48, 8>(),
+        make_variant16<24, 16>(),
     };
     *n = (int)(sizeof(v) / sizeof(v[0]));
     return v;
@@ -2771,17 +2852,18 @@ SwgKernelInfo swg_variant_info(int bits, int variant)
 }
 
 hipError_t swg_launch_fill(int bits, int variant, int W, int workgroups, const SwgFillParams &p,
-                           hipStream_t stream)
+                           hipStream_t stream, bool f16)
 {
     int n;
     const Variant *v = variants(bits, &n);
     if (variant < 0 || variant >= n || W < 1 || W > v[variant].info.max_waves || workgroups < 1)
         return hipErrorInvalidValue;
+    auto k = f16 ? v[variant].kernel_f16 : v[variant].kernel;
+    if (!k) return hipErrorInvalidValue;
     const size_t lds = v[variant].info.lds_per_wave * (size_t)W + v[variant].info.lds_fixed;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(v[variant].kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(v[variant].kernel, dim3(workgroups), dim3(W * 64), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(workgroups), dim3(W * 64), lds, stream, p);
     return hipGetLastError();
 }
 

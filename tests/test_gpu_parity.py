@@ -51,7 +51,15 @@ def test_golden_through_search(swg, ctx, name, engine, cells):
     scores, hits, st = ctx.search(db, k=10)
     ctx.set_option("f16", 1)
     assert np.array_equal(scores, _truth(g)), (name, st)
-    if cells == "int16" or engine == 1 or not gaps_ok:
+    if engine == 1 and gaps_ok and cells != "int16":
+        # the systolic engine takes the packed-f16 cells exactly where no score of the search can reach their ceiling
+        # (it has no flag-and-re-run route): longest sequence x largest table entry, or the query's best total
+        lens = np.diff(g["offsets"].astype(np.int64))
+        bound = min(int(g["sub"][g["query"].astype(np.int64)].max(axis=1).clip(min=0).sum()),
+                    min(len(g["query"]), (int(lens.max()) + 3) // 4 * 4) * int(g["sub"].max()))
+        assert st["cell_form"] == (2 if bound < 4096 else 0), (bound, st)
+        assert bound >= 4096 or st["n_rescored"] == 0
+    elif cells == "int16" or engine == 1 or not gaps_ok:
         assert st["cell_form"] in (0, 1)
     elif cells == "f16":
         assert st["cell_form"] == 2 and st["n_rescored"] == int((_truth(g) >= 4096).sum()), st
