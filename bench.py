@@ -19,7 +19,8 @@ value(N) / (N * value(1)) compares one workload with itself (it is the configura
 target on, and it fits one GPU: 3.8 GB of residues).  The `configs` object holds one block of the same shape for each
 of configs 3 (round 3's headline), 2, 4 (one GPU's eighth of the 10M-sequence database), "4_relatives" (that share
 with a family of 30-70 %-identity relatives of the query: the f16 flag-and-re-run route, first search and steady
-state), 5 and 5's stress variant, and "4_whole" repeats the headline's block.
+state), 5 and 5's stress variant, "peptides" (not a BASELINE shape: 2 million sequences of 20-40 residues, which the
+cost model hands to the systolic engine), and "4_whole" repeats the headline's block.
 
 N > 1 (one rank per GPU, torch.distributed over RCCL; SWG_BENCH_FORCE_DIST=1 rehearses the path with
 one rank): config 4 as ONE 10M-sequence database.  Every rank derives the same global length order,
@@ -72,6 +73,9 @@ CONFIGS = {
     # sequences are copies of the 3000-aa query at 30-70 % identity, scores about 3 800 .. 10 000 -- above the f16
     # cells' ceiling (4096), below int16's: the database on which the flag-and-re-run route is really taken
     7: dict(lq=3000, n=1250000, matrix="BLOSUM62", similar=0.005, subst=0.3, subst_hi=0.7),
+    # not a BASELINE configuration: a database of very short sequences (2 million peptides of 20-40 residues, block
+    # "peptides") -- the shape the lane groups are worst at and the cost model hands to the systolic engine
+    8: dict(lq=128, n=2000000, matrix="BLOSUM62", shape=dict(median=29.0, sigma_ln=0.25, min_len=20, max_len=40)),
 }
 # BASELINE.json names config 5 "forcing 16->32-bit rescore": its block carries, beside the library's own choice
 # (the wide int16 form, exact to 65535: nothing left to re-score), the same database with plain int16 cells,
@@ -253,6 +257,8 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
             flat, off = swg.synth_db(seed, n, min_len=a.uniform_len, max_len=a.uniform_len)
         elif a.max_len:
             flat, off = swg.synth_db(seed, n, max_len=a.max_len)
+        elif cfg.get("shape"):
+            flat, off = swg.synth_db(seed, n, **cfg["shape"])
         else:
             flat, off = swg.synth_db(seed, n)
         index = None
@@ -355,9 +361,11 @@ def run_config(env, cnum, steps, warmup, sharded=False, n_override=0, host_inclu
                         "%s, gaps %d/%d, global top-%d by one RCCL all-reduce" % (cnum, lq, n, env.world, cfg["matrix"], a.gapopen, a.gapextend, K))
         else:
             workload = ("config %s: 1 query (%d aa) vs %d-seq synthetic protein DB%s, %s, gaps %d/%d, top-%d"
-                        % ({6: "5 (stress variant)", 7: "4 (relatives)"}.get(cnum, str(cnum)), lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], a.gapopen, a.gapextend, K))
+                        % ({6: "5 (stress variant)", 7: "4 (relatives)", 8: "peptides"}.get(cnum, str(cnum)), lq, n, " per GPU" if env.world > 1 else "", cfg["matrix"], a.gapopen, a.gapextend, K))
             if cnum == 4 and not n_override:
                 workload += " (one GPU's eighth of the 10M-sequence database)"
+            if cfg.get("shape"):
+                workload += ", sequences of %d-%d residues" % (cfg["shape"]["min_len"], cfg["shape"]["max_len"])
             if cfg.get("subst_hi"):
                 workload += ", %g %% of the sequences relatives of the query (%d-%d %% identity)" % (
                     100 * cfg["similar"], round(100 * (1 - cfg["subst_hi"])), round(100 * (1 - cfg["subst"])))
@@ -427,7 +435,9 @@ def plan_of(last):
             "last_pass_cols": last["last_pass_cols"],
             "workgroups": last["workgroups"], "n_rescored": last["n_rescored"],
             "engine": {1: "systolic", 2: "diagonal"}.get(last["engine"]), "group_lanes": last["group_lanes"],
-            "cells": {0: "packed int16", 1: "packed int16, wide form (to 65535)",
+            "cells": "packed f16, three-operand maxima (systolic engine: taken where no score can reach 4096)"
+                     if last["engine"] == 1 and last["path_bits"] == 16 and last["cell_form"] == 2 else
+                     {0: "packed int16", 1: "packed int16, wide form (to 65535)",
                       2: "packed f16, three-operand maxima (exact below 4096; flagged pairs run again on int16 cells, int32 only beyond those)",
                       4: "packed f16 for sequences under %d rows, wide int16 form for the longer ones "
                          "(what the f16 cells flag all the same: the wide form again)" % last["split_rows"],
@@ -860,6 +870,7 @@ def main():
             blocks["4_relatives"] = run_config(env, 7, max(2, K // 5), min(W, 2), first_search_leg=True)
             blocks["5"] = run_config(env, 5, 2, 1, legs=CONFIG_LEGS[5])
             blocks["5_stress"] = run_config(env, 6, 2, 1, legs=CONFIG_LEGS[6])
+            blocks["peptides"] = run_config(env, 8, K, max(W, 30))
             if "host_inclusive" in blocks["2"]:
                 out["host_inclusive"] = blocks["2"]["host_inclusive"]      # quoted on config 2, as in round 1
         blocks["4_whole"] = {k: v for k, v in head.items() if k != "cpu_baseline"}

@@ -3027,6 +3027,7 @@ static int fill_batches16_device(swg_ctx *ctx, const swg_batch16 *batches, size_
     db->rows_padded = 0;
     // one macro-batch has nothing to tell the next: plans and hints start afresh with the cache's database
     db->tuned.clear();
+    db->pair_rows_prefix.clear(); // (the lengths changed under the same pair count)
     db->sat_hint = -1;
     db->f16_veto_epoch = 0;
     SwgPairTokens &T = db->ptok;

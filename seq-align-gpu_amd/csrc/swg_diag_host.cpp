@@ -20,16 +20,25 @@ static const double kHotCycles = 13.0;
 
 uint64_t swg_db_pair_count(const swg_db *db) { return (db->n_local + 1) / 2; }
 
+// Rows of the pairs [pair_begin, pair_end) (two reset rows + the longer sequence's residues each) and the longest of
+// them.  The planner asks on every search, for prefixes of the sorted order: a prefix sum, built on first use (8 bytes per
+// pair), makes that O(1) -- the loop it replaces walked 5 million pairs per search of the 10M-sequence database and, for
+// 2 million peptides, cost more than the fill (round 4: step 1.39 ms for a 0.97 ms fill).
 uint64_t swg_db_pair_rows(const swg_db *db, uint64_t pair_begin, uint64_t pair_end, uint64_t *longest_rows)
 {
-    uint64_t total = 0, longest = 0;
-    for (uint64_t p = pair_begin; p < pair_end; ++p) {
-        const uint64_t r = 2ull + db->lens[2 * p];
-        total += r;
-        longest = std::max(longest, r);
+    const uint64_t n = swg_db_pair_count(db);
+    std::vector<uint64_t> &pre = const_cast<swg_db *>(db)->pair_rows_prefix;
+    if (pre.size() != n + 1) {
+        pre.assign(n + 1, 0);
+        for (uint64_t p = 0; p < n; ++p) pre[p + 1] = pre[p] + 2ull + db->lens[2 * p];
     }
-    if (longest_rows) *longest_rows = longest;
-    return total;
+    pair_end = std::min(pair_end, n);
+    if (pair_begin >= pair_end) {
+        if (longest_rows) *longest_rows = 0;
+        return 0;
+    }
+    if (longest_rows) *longest_rows = 2ull + db->lens[2 * pair_begin]; // (sorted longest first)
+    return pre[pair_end] - pre[pair_begin];
 }
 
 uint64_t swg_db_pairs_longer_than(const swg_db *db, uint64_t rows)

@@ -126,6 +126,7 @@ struct swg_db {
     std::vector<uint64_t> code_off; // [n_bins*128+1] byte offsets into codes (multiples of 4)
     SwgPairTokens ptok;             // pair-major tokens (work-queue form of the diagonal engine)
     SwgDiagLayout diag[2];          // stream layouts of the diagonal engine: [0] bulk, [1] long pairs
+    std::vector<uint64_t> pair_rows_prefix; // rows of the pairs before pair p (swg_db_pair_rows: built on first use)
     std::map<uint64_t, SwgTuned> tuned; // query length -> engine + geometry that measured fastest on this device
     // What the last finished search of this database saw (plans of later searches only: results never depend
     // on it).  sat_hint: sequences its 16-bit fill flagged for the re-score (-1: no search yet), by which

@@ -39,7 +39,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["config"]["n_seqs"] == 10000000 and d["config"]["lq"] == 3000
     assert d["roofline"]["launches_per_step"] == 48 and d["roofline"]["traffic_source"].endswith("#config4_whole_f16")
     _check_block(d)
-    assert set(d["configs"]) == {"2", "3", "4", "4_relatives", "4_whole", "5", "5_stress"}
+    assert set(d["configs"]) == {"2", "3", "4", "4_relatives", "4_whole", "5", "5_stress", "peptides"}
     names = {"5_stress": "5 (stress variant)", "4_relatives": "4 (relatives)", "4_whole": "4"}
     for k, b in d["configs"].items():
         assert b["config"]["workload"].startswith("config %s:" % names.get(k, k))
@@ -61,6 +61,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert cr["config"]["n_seqs"] == 1250000 and cr["first_search"]["n_rescored"] > 0 and cr["first_search"]["cell_form"] == 2
     assert cr["steady_state"]["n_rescored"] == cr["first_search"]["n_rescored"] and cr["steady_state"]["rescore_ms"] > 0
     assert cr["kernel_ms"]["rescore"] > 0 and cr["verify"]["ok"] is True
+    # short sequences: the cost model's engine choice, timed by the driver like everything else
+    pe = d["configs"]["peptides"]
+    assert pe["config"]["engine"] == "systolic" and pe["dtype"] == "f16" and pe["roofline"]["binding_roof"]["instr_per_cell"] == 4.25
+    assert pe["value"] > 6000
     for b in (d, d["configs"]["2"], d["configs"]["3"], d["configs"]["4"]):
         assert b["dtype"] == "f16" and b["roofline"]["binding_roof"]["instr_per_cell"] == 4.25
         assert b["roofline"]["traffic"] is None or b["roofline"]["traffic_source"].startswith("profiles/traffic.json@sha256:")
