@@ -2588,6 +2588,15 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
                                   (double)std::min(n_queries, Qb_max), form) > 0;
         for (int c = 0; fast && c < wk.n_classes; ++c)
             fast = wk.plan[c].npass == 1 && diag_class_is_dynamic(ctx, db, wk.plan[c]) && (size_t)wk.plan[c].G * wk.plan[c].K >= lq_max;
+        // A database of short sequences is faster on the systolic engine, one query after another (no batch form of
+        // that engine exists), than as a batch on the lane groups: 16 queries against 500 000 peptides 3 720 GCUPS as a
+        // batch, ~7 000 one by one.  Same comparison as a single search makes (swg_search_begin), per query.
+        if (fast && ctx->opt_engine == 0 && ctx->opt_f16 != 2 && !db->tokens_only && wk.plan[0].est_ms > 0.0) {
+            int sys_K = 0;
+            const bool sys_f16 = ctx->opt_f16 != 0 && -go <= 2048 && -ge <= 2048 && bound_max < 4096ull;
+            const double sys_ms = swg_systolic_estimate_ms(db, lq_max, ctx->n_cu, &sys_K, sys_f16) * (double)std::min(n_queries, Qb_max);
+            if (sys_K > 0 && sys_ms < SWG_SYSTOLIC_MARGIN * wk.plan[0].est_ms * swg_diag_short_pair_factor(db, wk.plan[0], form)) fast = false;
+        }
     }
     if (!fast) {
         // one after another; the context's own query is put back afterwards

@@ -848,11 +848,13 @@ def test_pairs_claimed_by_the_batch(swg, ctx, orc):
             _reset_options(ctx)
             qs = [swg.synth_query(600 + i, L) for i, L in enumerate((30, 64, 17))]
             db = swg.Database(flat, off).upload(ctx)
-            for opts in ({}, {"batch_blocks": 100000}, {"qq": 0, "batch": 3}):
+            for opts in ({"engine": 2}, {"engine": 2, "batch_blocks": 100000}, {"engine": 2, "qq": 0, "batch": 3}, {}):
+                # (engine 2: the batch on the lane groups; left alone such a database goes query by query to the systolic engine)
                 _reset_options(ctx)
                 for k, v in opts.items():
                     ctx.set_option(k, v)
                 got, _, st = ctx.search_multi(db, qs)
+                assert not opts or st["engine"] == 2, (name, opts, st)
                 for i, q in enumerate(qs):
                     assert np.array_equal(got[i], orc.score_db(q, flat, off, sc.table(), -2, -1)), (name, opts, i, st)
             db.close()
