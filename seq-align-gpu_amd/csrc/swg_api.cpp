@@ -2616,6 +2616,7 @@ static int search_multi_impl(swg_ctx *ctx, const swg_db *db, const int8_t *queri
                 st.n_rescored += one.n_rescored;
                 st.cells_padded += one.cells_padded;
                 st.path_bits = one.path_bits;
+                st.cell_form = one.cell_form;
                 st.engine = one.engine;
                 st.cols_per_wave = one.cols_per_wave;
                 st.group_lanes = one.group_lanes;
