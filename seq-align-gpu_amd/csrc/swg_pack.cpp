@@ -48,6 +48,13 @@ static void derive_tables(swg_db *db)
     db->n_local = n_local;
     db->residues = residues;
     db->rows_padded = rows_padded;
+    // rows of the pairs before pair p (two reset rows + the longer sequence): what the planner sums on every search
+    // (swg_db_pair_rows); built here, once, so that searches never write to the database's host image
+    {
+        const size_t n_pairs = (n_local + 1) / 2;
+        db->pair_rows_prefix.assign(n_pairs + 1, 0);
+        for (size_t p = 0; p < n_pairs; ++p) db->pair_rows_prefix[p + 1] = db->pair_rows_prefix[p] + 2ull + db->lens[2 * p];
+    }
     db->max_nblk = nb ? *std::max_element(db->bin_nblk.begin(), db->bin_nblk.end()) : 0;
 }
 
@@ -180,8 +187,19 @@ int swg_pack_shards(const int8_t *flat, const uint64_t *offsets, size_t n, int s
         if (rcs[r] != SWG_OK && errs[r].empty()) errs[r] = swg_global_error(); // (thread-local: carried to the caller's thread below)
     };
     std::vector<std::thread> pool;
-    for (int r = 1; r < shard_count; ++r) pool.emplace_back(work, r);
+    pool.reserve((size_t)shard_count);
+    int started = 1; // shards 0 .. started-1 have a worker (shard 0: this thread)
+    try {
+        for (int r = 1; r < shard_count; ++r) {
+            pool.emplace_back(work, r);
+            started = r + 1;
+        }
+    } catch (const std::exception &) {
+        // (no more threads to be had: the shards without one are built here, after the others -- a joinable std::thread
+        // must not be destroyed, so nothing may leave this function before the joins below)
+    }
     work(0);
+    for (int r = started; r < shard_count; ++r) work(r);
     for (std::thread &t : pool) t.join();
     for (int r = 0; r < shard_count; ++r)
         if (rcs[r] != SWG_OK) {
