@@ -517,7 +517,15 @@ double swg_systolic_estimate_ms(const swg_db *db, size_t lq, int n_cu, int *best
         const double waves_per_simd = std::max(1.0, per_cu * W / 4.0);
         const double instr = (f16 ? 8.5 : 10.0) * info.K + 12.0; // (packed-f16 cells where no score can reach 4096)
         const double thr = (rows * W * instr * 4.06 + (double)db->n_bins * W * 5000.0) / (4.0 * n_cu);
-        const double chain = longest * instr * 4.06 * std::min(4.0, waves_per_simd);
+        // bins are whole work units of a workgroup: with few bins per workgroup the search lasts as many ROUNDS as the
+        // busiest workgroup has bins -- the first of them the longest bin (bins go out longest first), the others about
+        // average -- at the rate of a wavefront that shares its SIMD (300 000 sequences of ~250 residues, lq 64: 2 344
+        // bins on 1 536 workgroups are two rounds, 0.97 ms measured where the throughput term alone says 0.58)
+        const double wps = std::min(4.0, waves_per_simd);
+        const double n_wgs = std::max(1.0, (double)n_cu * per_cu);
+        const double rounds = std::ceil((double)db->n_bins / n_wgs);
+        const double quant = (longest + (rounds - 1.0) * rows / (double)db->n_bins) * instr * 4.06 * wps;
+        const double chain = std::max(longest * instr * 4.06 * wps, quant);
         // (the 24-column instantiation measures 30 % over its count -- peptides lq 128: 1.48 ms against 1.05 for 8 x 16 columns --
         // and is only picked where that still wins)
         const double ms = std::max(thr, chain) / 2.4e6 * (info.K == 24 ? 1.3 : 1.0);
