@@ -53,6 +53,11 @@ Rccl g_rccl;
 struct swg_group {
     int n = 0;
     bool force_collective = false; // run the all-reduce even with one device (rehearsal)
+    // several contexts on ONE device (a device named more than once: the rehearsal of n > 1 on a one-GPU box): RCCL refuses
+    // duplicate devices, so the shards' keys are merged on the host -- which is what the max-all-reduce of disjoint
+    // segments computes.  Everything else of the group path (one sort, shards built and uploaded side by side, all
+    // searches queued before any is awaited, alignments routed to the shard that holds the sequence) runs as with n devices.
+    bool host_merge = false;
     std::vector<int> devices;
     std::vector<swg_ctx *> ctx;
     std::vector<swg_db *> db;
@@ -110,7 +115,10 @@ extern "C" int swg_group_create(const int *devices, int n, int force_collective,
     }
     g->db.assign(n, nullptr);
     g->d_keys.assign(n, nullptr);
-    if (n > 1 || g->force_collective) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (g->devices[i] == g->devices[j]) g->host_merge = true;
+    if ((n > 1 || g->force_collective) && !g->host_merge) {
         if (!g_rccl.load()) {
             swg_group_destroy(g);
             return swg_set_global_error(SWG_ERR_HIP, "swg_group_create: cannot load librccl (%s)", dlerror());
@@ -223,7 +231,7 @@ extern "C" int swg_group_search(swg_group *g, int32_t *scores_out, swg_hit *topk
     if (first_err != SWG_OK) return first_err;
     if (k == 0) return SWG_OK;
 
-    if (g->n > 1 || g->force_collective) {
+    if ((g->n > 1 || g->force_collective) && !g->host_merge) {
         // each device holds the n*k buffer with only its own segment filled; one max-all-reduce
         // leaves the union everywhere (n*k*8 bytes: latency-bound, link bandwidth irrelevant)
         const size_t count = (size_t)g->n * k;

@@ -965,6 +965,56 @@ def test_multipass_through_the_work_queue(swg, ctx, orc):
     _reset_options(ctx)
 
 
+def test_group_of_several_contexts_on_one_device(swg, orc):
+    """the in-process multi-GPU path had never run with n > 1.  A group that names this box's one
+    device two, four and five times holds that many contexts and shards: `swg_group_load` sorts the database ONCE and cuts,
+    builds and uploads the shards side by side (one host thread each), `swg_group_search` queues every shard's search
+    before it awaits any, scores land by original index, the top-K lists are merged, alignments are routed to the shard
+    that holds the sequence.  (RCCL refuses a device named twice, so the keys are merged on the host here -- which is what
+    the max-all-reduce of disjoint segments computes; the collective itself runs in test_group_with_rccl_merge.)"""
+    sc = swg.load_scoring("BLOSUM62")
+    q = swg.synth_query(33, 220)
+    flat, off = swg.synth_db(33, 3001, max_len=900)           # 24 bins: uneven shares for 5 shards, an odd sequence count
+    want = orc.score_db(q, flat, off, sc.table(), -2, -1)
+    for n in (2, 4, 5):
+        sorts = swg.lib.swg_debug_sort_count()
+        grp = swg.Group([0] * n)
+        grp.set_option("autotune", 0)
+        grp.set_scoring(sc, -2, -1)
+        grp.set_query(q)
+        grp.load(flat, off)
+        assert swg.lib.swg_debug_sort_count() == sorts + 1
+        scores, hits, stats = grp.search(k=60)
+        assert np.array_equal(scores, want) and hits == orc.topk(want, 60), n
+        assert len(stats) == n and sum(st["cells"] for st in stats) == len(q) * len(flat)
+        assert all(st["cells"] > 0 for st in stats)
+        none, hits2, _ = grp.search(want_scores=False, k=9)     # a second search on the resident shards, hits only
+        assert none is None and hits2 == orc.topk(want, 9)
+        als = grp.align_hits(hits[:8])                          # the eight best hits live on several shards
+        for a, (s_, i_) in zip(als, hits[:8]):
+            sc_, co, ops = orc.pair_trace(q, flat[int(off[i_]):int(off[i_ + 1])], sc.table(), -2, -1)
+            assert (a["score"], a["index"], a["ops"]) == (s_, i_, ops) and sc_ == s_
+        # another query against the same resident shards
+        q2 = swg.synth_query(34, 90)
+        grp.set_query(q2)
+        scores2, hits3, _ = grp.search(k=5)
+        want2 = orc.score_db(q2, flat, off, sc.table(), -2, -1)
+        assert np.array_equal(scores2, want2) and hits3 == orc.topk(want2, 5)
+        grp.set_query(q)
+        grp.close()
+    # fewer bins than contexts: some shards are empty
+    flat1, off1 = swg.synth_db(35, 200, max_len=300)            # 2 bins, 4 contexts
+    grp = swg.Group([0, 0, 0, 0])
+    grp.set_scoring(sc, -2, -1)
+    grp.set_query(q)
+    grp.load(flat1, off1)
+    scores, hits, stats = grp.search(k=10)
+    want1 = orc.score_db(q, flat1, off1, sc.table(), -2, -1)
+    assert np.array_equal(scores, want1) and hits == orc.topk(want1, 10)
+    assert sorted(st["cells"] > 0 for st in stats) == [False, False, True, True]
+    grp.close()
+
+
 def test_group_with_rccl_merge(swg, orc):
     """swg_group on this box's one GPU with the collective forced: shard packing, concurrent
     begin/end, the RCCL max-all-reduce of the hit keys and the final merge all run; results are
