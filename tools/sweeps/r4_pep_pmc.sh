@@ -13,8 +13,8 @@ for sub in ("sq", "lds", "act"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True):
         for r in csv.DictReader(open(f)):
-            if "swg_diag_dyn" in r["Kernel_Name"]:
-                acc[r["Kernel_Name"][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "swg_diag_dyn" in r["Kernel_Name"] or "swg_fill_kernel" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"][:56]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         print(sub, k, {c: round(sum(v) / len(v)) for c, v in d.items()}, "launches", len(next(iter(d.values()))))
 PY
