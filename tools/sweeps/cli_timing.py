@@ -25,13 +25,16 @@ cli = os.path.join(ROOT, "seq-align-gpu_amd", "bin", "smith_waterman")
 mat = os.path.join(ROOT, "seq-align-gpu_amd", "data", "PAM250.txt")
 for extra in ([], ["--topk", "100", "--align"], ["--savedb", "/tmp/cli/db.swg"], ["--packed"]):
     dbf = "/tmp/cli/db.swg" if "--packed" in extra else "/tmp/cli/db.fa"
-    for rep in range(2):
+    walls = []
+    for rep in range(7):
         t0 = time.time()
         r = subprocess.run([cli, "--substitution_matrix", mat, "--timing"] + extra + ["--files", "/tmp/cli/q.fa", dbf],
                            stdout=open("/tmp/cli/out.txt", "wb"), stderr=subprocess.PIPE, text=True,
                            env=dict(os.environ, SWG_TIMING="1") if not extra else None)   # (plain run: swg_create's own breakdown too)
-        wall = time.time() - t0
-    print("== %s: exit %d, wall %.0f ms (second run), stdout %.1f MB" % (" ".join(extra) or "plain", r.returncode, wall * 1e3,
+        walls.append((time.time() - t0) * 1e3)
+    wall = sorted(walls[1:])[len(walls[1:]) // 2] / 1e3     # median of six runs after the first
+    print("   walls of runs 2-7, ms: " + " ".join("%.0f" % w for w in walls[1:]))
+    print("== %s: exit %d, wall %.0f ms (median of runs 2-7), stdout %.1f MB" % (" ".join(extra) or "plain", r.returncode, wall * 1e3,
                                                                     os.path.getsize("/tmp/cli/out.txt") / 1e6))
     print(r.stderr, flush=True)
     print(subprocess.run(["tail", "-2", "/tmp/cli/out.txt"], stdout=subprocess.PIPE, text=True).stdout if not extra else "", flush=True)
