@@ -1456,7 +1456,15 @@ static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess,
     out->variant = best;
     out->K = bestK;
     out->G = G;
-    out->W = 4;
+    // One workgroup per CU is all that fits beside a 64-lane profile of 512 columns or more (98 KB at K = 24), so the
+    // workgroup is as large as the kernel was compiled for, and the kernel sends home the wavefronts a shorter list
+    // does not need (it knows the list's length; the host does not).  Until round 4's last day the workgroup had 4
+    // wavefronts -- ONE per SIMD, 5.2 cycles per instruction instead of 4.07 -- whatever the list, and config 4's
+    // 3 100 pairs took three rounds and 28 left-overs on 1 024 wavefronts (7.7 ms per pass, now 5.3; the text of
+    // DESIGN 9 counted 3 072).
+    int W = swg_diag_variant_info(best).max_waves / 4 * 4;
+    while (W > 4 && swg_diag_dyn_lds_bytes(bestK, G, W) > 160 * 1024) W -= 4;
+    out->W = std::max(4, W);
     out->npass = (int)npass;
     return true;
 }

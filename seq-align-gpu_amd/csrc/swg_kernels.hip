@@ -1031,6 +1031,15 @@ __global__ __launch_bounds__(MAXW * 64) void swg_diag_dyn_kernel(const SwgDiagDy
         if (g < 4) st[g] = 0u; // every group is due at block 0
     }
     __syncthreads();
+    // List mode: the host sizes the workgroup for a long list (the count is on the device); of a shorter one's only
+    // the wavefronts the list can keep busy stay, in fours -- one more per SIMD.  The queue gives a pair to whoever
+    // asks first, and the sixteen wavefronts of the first workgroups would each run theirs at a quarter of the speed
+    // that four have.  (The one barrier of the kernel is behind them.)
+    if (p.list) {
+        const uint32_t per_wave = 64u >> gshift;
+        const uint32_t want = (n_list + gridDim.x * per_wave - 1u) / (gridDim.x * per_wave);
+        if ((uint32_t)w >= max(4u, (want + 3u) & ~3u)) return;
+    }
 
     CellsDiag<K, FORM> cells;
     cells.reset();
