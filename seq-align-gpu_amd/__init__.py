@@ -184,6 +184,7 @@ _sig("swg_debug_sort_count", C.c_ulong, [])
 _sig("swg_debug_engine", C.c_int, [_vp, C.c_size_t, C.c_int, C.c_int, _vp])
 _sig("swg_debug_plan", C.c_int, [_vp, C.c_size_t, C.c_int, _vp])
 _sig("swg_debug_split", C.c_int, [_vp, C.c_size_t, C.c_uint64, _vp])
+_sig("swg_debug_list_plan", C.c_int, [C.c_size_t, C.c_uint32, C.c_int, _vp, _vp])
 _sig("swg_debug_pair_tokens", C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)])
 
 
@@ -326,6 +327,15 @@ def synth_db_shard(seed, n, shard_rank, shard_count, median=290.0, sigma_ln=0.75
     residues = _take(flat, int(offsets[n_local]), np.int8)
     return dict(flat=residues, offsets=offsets, index=index, n_total=n, residues_total=int(tot.value),
                 planted=int(npl.value))
+
+
+def debug_list_plan(lq, n_pairs_guess, n_cu=256, main=(32, 16, 4)):
+    """Test hook: geometry of the int16 re-run of the pairs the f16 cells flagged (no device needed)
+    -> dict(K, G, W, passes)."""
+    m = np.asarray(main, dtype=np.int32)
+    out = np.zeros(4, dtype=np.int32)
+    _check(lib.swg_debug_list_plan(lq, n_pairs_guess, n_cu, m.ctypes.data_as(_vp), out.ctypes.data_as(_vp)))
+    return {"K": int(out[0]), "G": int(out[1]), "W": int(out[2]), "passes": int(out[3])}
 
 
 def synth_query(seed, lq):

@@ -1424,7 +1424,7 @@ static int launch_q32(swg_ctx *ctx, const swg_db *db, const SwgDiagWork &wk, int
 // kernel's 32-bit edge indices -- on databases of any size.  The launch reads the list's length on the device
 // and leaves at once when it is empty.  Geometry: few pairs get 64 lanes each (the shortest chain per row),
 // many the main fill's own.
-static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess, const SwgDiagPlan &main_plan, SwgDiagPlan *out)
+static bool i16_list_plan(int n_cu, size_t lq, uint32_t n_pairs_guess, const SwgDiagPlan &main_plan, SwgDiagPlan *out)
 {
     // 64 lanes per pair: one pair per wavefront, so a list shorter than the launch has lane groups still fills every
     // wavefront it occupies (with 16-lane groups a list of 3 100 pairs -- config 4's share with 0.5 % relatives --
@@ -1432,7 +1432,7 @@ static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess,
     // 15), and at 512 columns or more its rows cost the same instructions per pair as the main fill's narrower groups
     // in more passes (lq 3000: 2 x 269 per pair-row against 6 x 349 / 4).  Only a short query's long list -- where a
     // 64-lane group would hold two or three columns per lane -- keeps the main fill's geometry.
-    if (n_pairs_guess > 4u * (uint32_t)ctx->n_cu && lq < 512) {
+    if (n_pairs_guess > 4u * (uint32_t)n_cu && lq < 512) {
         *out = main_plan;
         out->f16 = 0;
         out->f16_from = 0;
@@ -1467,6 +1467,24 @@ static bool i16_list_plan(const swg_ctx *ctx, size_t lq, uint32_t n_pairs_guess,
     out->W = std::max(4, W);
     out->npass = (int)npass;
     return true;
+}
+
+// test hook (not in the public headers): the list re-run's geometry for a query of lq columns, on the host.
+// main_kgw: the main fill's (K, G, W), which a short query's long list keeps; out: {K, G, W, passes}
+extern "C" int swg_debug_list_plan(size_t lq, uint32_t n_pairs_guess, int n_cu, const int32_t *main_kgw, int32_t *out)
+{
+    if (!main_kgw || !out || n_cu < 1) return SWG_ERR_ARG;
+    SwgDiagPlan mp, lp;
+    mp.K = main_kgw[0];
+    mp.G = main_kgw[1];
+    mp.W = main_kgw[2];
+    mp.npass = 1;
+    if (!i16_list_plan(n_cu, lq, n_pairs_guess, mp, &lp)) return SWG_ERR_ARG;
+    out[0] = lp.K;
+    out[1] = lp.G;
+    out[2] = lp.W;
+    out[3] = lp.npass;
+    return SWG_OK;
 }
 
 static int launch_dyn_list(swg_ctx *ctx, swg_db *db, const SwgDiagPlan &pl, bool wide, int go, int ge, const uint32_t *d_list,
@@ -2095,7 +2113,7 @@ static int search_begin(swg_ctx *ctx, const swg_db *db, bool want_scores, size_t
                                                       db->d_counters + 16, db->d_lens, db->d_counters + 6, s));
         SwgDiagPlan lp;
         const uint32_t guess = db->sat_hint > 0 ? (uint32_t)std::min<long long>(db->sat_hint, 1ll << 30) : 1u;
-        if (!i16_list_plan(ctx, lq, guess, wk.plan[0], &lp)) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no geometry for the int16 re-run");
+        if (!i16_list_plan(ctx->n_cu, lq, guess, wk.plan[0], &lp)) return swg_set_ctx_error(ctx, SWG_ERR_ARG, "no geometry for the int16 re-run");
         HIP_TRY(ctx, hipMemsetAsync(db->d_counters + SWG_QUEUE_WORD(0), 0, (size_t)(SWG_COUNTER_BYTES - SWG_QUEUE_WORD(0) * 4u), s));
         if ((rc = launch_dyn_list(ctx, const_cast<swg_db *>(db), lp, rerun_wide, go, ge, db->d_list, db->d_counters + 17, s)) != SWG_OK) return rc;
         level_ceiling = rerun_wide ? 65535 : 32767;

@@ -162,3 +162,19 @@ def test_engine_choice_short_sequences_go_systolic(swg):
         for lq in lqs:
             assert not db.debug_engine(lq)["systolic"], (n, lq)
         db.close()
+
+
+def test_list_rerun_takes_a_full_size_workgroup(swg):
+    """The int16 re-run of what the f16 cells flagged: 64 lanes per pair from 512 columns up, and -- one workgroup per
+    CU is all that fits beside such a profile -- a workgroup of as many wavefronts as the kernel was compiled for (the
+    kernel trims it to the list's length, which only the device knows).  Until the end of round 4 it had four: one
+    wavefront per SIMD whatever the list (config 4's share with relatives: 15.4 -> 10.7 ms)."""
+    assert swg.debug_list_plan(3000, 1) == {"K": 24, "G": 64, "W": 16, "passes": 2}
+    assert swg.debug_list_plan(3000, 3100) == {"K": 24, "G": 64, "W": 16, "passes": 2}       # (no guess involved)
+    p = swg.debug_list_plan(8192, 1)
+    assert (p["G"], p["passes"]) == (64, 4) and p["K"] == 32 and p["W"] == 12, p               # K = 32 is compiled for 12
+    p = swg.debug_list_plan(600, 1)
+    assert (p["K"], p["G"], p["W"], p["passes"]) == (10, 64, 16, 1), p
+    # a short query's long list keeps the main fill's geometry
+    assert swg.debug_list_plan(367, 5000, main=(23, 16, 4)) == {"K": 23, "G": 16, "W": 4, "passes": 1}
+    assert swg.debug_list_plan(367, 100, main=(23, 16, 4))["G"] == 64
