@@ -476,7 +476,9 @@ def roofline_of(a, last, fill_ms, cells_local, cnum, sharded):
     # (counters are collected per configuration and cell form as bench.py --config C runs it; a leg without a
     # measurement of its own gets null rather than a neighbour's figure)
     table, source = _traffic_table(a.traffic_json)
-    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {1: "_wide", 2: "_f16", 4: "_split", 5: "_split16"}.get(form, "") if q16 else "_int32")
+    sys16 = last["engine"] != 2 and last["path_bits"] == 16     # the systolic engine's 16-bit cells
+    key = "config%d%s%s" % (cnum, "_whole" if sharded else "", {1: "_wide", 2: "_f16", 4: "_split", 5: "_split16"}.get(form, "") if q16
+                            else ("_systolic_f16" if int(last["cell_form"]) == 2 else "_systolic") if sys16 else "_int32")
     traffic = table.get(key, {}).get("hbm_bytes_per_launch")
     # The binding roof is VALU issue, reported beside the (by construction tiny) HBM fraction: one wave64 packed
     # instruction per SIMD every 4 cycles (16 lanes per cycle) at 2.4 GHz.  Instructions per cell: 5 for the packed

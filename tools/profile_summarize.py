@@ -18,8 +18,12 @@ json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 # bytes, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes, mean per launch
 # (the main fill only: "diag_dyn" / "fill_kernel"; a configuration's re-score leg runs swg_diag32q_kernel, listed in the summary)
 fill = {k: cs for k, cs in summary["pmc_mean_per_launch"].items() if ("diag_dyn" in k or "diag_kernel" in k or "fill_kernel" in k) and "FETCH_SIZE" in cs}
-if KEY.endswith("_split"):   # both 16-bit forms in one search: the dominant kernel's launches only (the f16 cells, FORM 2)
-    fill = {k: cs for k, cs in fill.items() if k.rstrip().endswith(", 2>")}
+# KERNEL_SUFFIX=", 1>" (environment): only the fill kernels whose name ends so -- a run whose legs use different cell forms
+# (bench.py --config 6: the wide form, then plain int16) -- and their mean per dispatch, as for the split keys
+SUFFIX = os.environ.get("KERNEL_SUFFIX", "")
+PER_DISPATCH = KEY.endswith("_split") or KEY.endswith("_split16") or bool(SUFFIX)
+if PER_DISPATCH:   # both 16-bit forms in one search: the dominant kernel's launches only (the f16 cells, FORM 2)
+    fill = {k: cs for k, cs in fill.items() if k.rstrip().endswith(SUFFIX or ", 2>")}
 # per search: every fill dispatch's counters added up, divided by the searches the run made (one swg_zero2_kernel each);
 # per launch: that divided by LAUNCHES = bench.py's roofline.launches_per_step (passes x segments; 1 for a single pass,
 # whose two classes run side by side as one step of the fill)
@@ -27,11 +31,15 @@ searches = max(1, len(ctr.get("swg_zero2_kernel", {}).get("FETCH_SIZE", [])))
 launches = max(1, int(sys.argv[5]) if len(sys.argv) > 5 else 1)
 fetch = sum(sum(ctr[k]["FETCH_SIZE"]) for k in fill) / searches / launches
 write = sum(sum(ctr[k].get("WRITE_SIZE", [0.0])) for k in fill) / searches / launches
-if KEY.endswith("_split"):   # (only some of the run's searches -- not its re-score leg's -- launch this kernel: its mean per dispatch)
+if PER_DISPATCH:   # (only some of the run's searches -- not its re-score leg's -- launch this kernel: its mean per dispatch)
     fetch = sum(cs["FETCH_SIZE"] for cs in fill.values())
     write = sum(cs.get("WRITE_SIZE", 0.0) for cs in fill.values())
+HOW_PD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/traffic_only.sh / profile_bench.sh): the MEAN PER DISPATCH of "
+          "the fill kernel whose name ends '%s' (the run's legs use several cell forms; a launch of bench.py's roofline is one such dispatch); "
+          "KiB -> bytes; FETCH_SIZE doubled (gfx950 correction of the guide's HBM section; factor 2.000 measured for these kernels' load "
+          "shapes: profiles/r03_fetch_size_probe.txt)" % (SUFFIX or ", 2>"))
 json.dump({KEY: {"hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
-           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh): the counters of every fill dispatch of the run added up, divided by its searches and by the launches of one search's fill (%d here: bench.py's roofline.launches_per_step); KiB -> bytes; FETCH_SIZE doubled (gfx950 correction of the guide's HBM section; factor 2.000 measured for these kernels' load shapes: profiles/r03_fetch_size_probe.txt)" % launches,
+           "how": HOW_PD if PER_DISPATCH else "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh): the counters of every fill dispatch of the run added up, divided by its searches and by the launches of one search's fill (%d here: bench.py's roofline.launches_per_step); KiB -> bytes; FETCH_SIZE doubled (gfx950 correction of the guide's HBM section; factor 2.000 measured for these kernels' load shapes: profiles/r03_fetch_size_probe.txt)" % launches,
            "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "searches": searches, "launches_per_search": launches,
            "kernels": {k: {"FETCH_SIZE": cs["FETCH_SIZE"], "WRITE_SIZE": cs.get("WRITE_SIZE", 0.0)} for k, cs in fill.items()}}},
           open(out + "/traffic.json", "w"), indent=1)
