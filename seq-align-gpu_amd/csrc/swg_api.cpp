@@ -1474,7 +1474,7 @@ static bool i16_list_plan(int n_cu, size_t lq, uint32_t n_pairs_guess, const Swg
 extern "C" int swg_debug_list_plan(size_t lq, uint32_t n_pairs_guess, int n_cu, const int32_t *main_kgw, int32_t *out)
 {
     if (!main_kgw || !out || n_cu < 1) return SWG_ERR_ARG;
-    SwgDiagPlan mp, lp;
+    SwgDiagPlan mp = SwgDiagPlan(), lp = SwgDiagPlan();
     mp.K = main_kgw[0];
     mp.G = main_kgw[1];
     mp.W = main_kgw[2];
